@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the assignment hot path on MI355X.
+
+metric   : N x N assignments/s = N / wall time of one full solve (BASELINE.json / SURVEY 8d)
+workload : g1  perf.jl:5 instance family, cost ~ U{10..40}, N = 16384 (BASELINE configs[2], the
+               configuration the north-star target is quoted on; fits one GPU).  A "step" is one
+               full pass of the hot path over one synthetic instance that is generated ON the
+               device: the 4*N^2-byte int32 cost write (synthetic stand-in for the cost-matrix
+               build: perf.jl draws the matrix directly) + td_assign (compress, auction bidding
+               rounds, augmenting-path finisher, total).  The optimum is known (10*N) and is
+               checked every step.
+           g2  greedy_opt.py geometry: positions -> td_cost_build (|a-b|) -> td_assign.
+           g3  Simulator.java tick shape: S=50, DROP_TIME threshold, dummy columns.
+--gpus N : one process per GPU (torch.distributed, RCCL).  Instances are independent objects:
+           every rank solves its own instance (different seed) with no data-path collective —
+           weak scaling; value = all instances' assignments / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--workload", default="g1", choices=["g1", "g2", "g3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    return ap.parse_args()
+
+
+class Workload:
+    """Device-resident synthetic instance + the step that solves it through the C ABI."""
+
+    def __init__(self, kind, n, seed, torch, td, ffi):
+        self.kind, self.n, self.seed = kind, n, seed
+        self.td, self.ffi, self.lib = td, ffi, ffi.lib()
+        self.cost = torch.empty((n, n), dtype=torch.int32, device="cuda")
+        self.r2c = torch.empty(n, dtype=torch.int32, device="cuda")
+        self.total = ctypes.c_int64(0)
+        rng = np.random.default_rng(seed)
+        if kind == "g2":
+            S = 10 * n
+            self.cab_to = torch.from_numpy(rng.integers(0, S, n).astype(np.int32)).cuda()
+            self.dem_from = torch.from_numpy(rng.integers(0, S, n).astype(np.int32)).cuda()
+            self.expected = int(np.abs(np.sort(self.cab_to.cpu().numpy().astype(np.int64)) -
+                                       np.sort(self.dem_from.cpu().numpy().astype(np.int64))).sum())
+            self.args = (-1, 250000)
+        elif kind == "g3":
+            S = 50
+            nd = max(1, int(0.363 * n))
+            self.cab_to = torch.from_numpy(rng.integers(0, S, n).astype(np.int32)).cuda()
+            self.dem_from = torch.from_numpy(rng.integers(0, S, nd).astype(np.int32)).cuda()
+            self.expected = None
+            self.args = (10, 250000)
+        else:
+            self.expected = 10 * n if n >= 1000 else None
+
+    def build(self):
+        if self.kind == "g1":
+            self.ffi.check(self.lib.td_gen_uniform(self.n, self.seed, 10, 40, 0, self.n, self.cost.data_ptr()))
+        else:
+            thr, fill = self.args
+            self.ffi.check(self.lib.td_cost_build(self.cab_to.data_ptr(), None, int(self.cab_to.numel()),
+                                                  self.dem_from.data_ptr(), None, int(self.dem_from.numel()),
+                                                  None, 0, fill, thr, 0, self.cost.data_ptr()))
+
+    def solve(self):
+        self.ffi.check(self.lib.td_assign(self.n, self.cost.data_ptr(), self.r2c.data_ptr(),
+                                          ctypes.byref(self.total), None))
+        return self.total.value
+
+    def step(self):
+        self.build()
+        t = self.solve()
+        if self.expected is not None and t != self.expected:
+            raise RuntimeError("wrong optimum: got %d expected %d" % (t, self.expected))
+        return t
+
+
+def kernel_profile(wl, ffi, reps):
+    """Per-kernel-class device time with HIP events recorded on the library's stream."""
+    lib = ffi.lib()
+    ffi.check(lib.td_profile_enable(1))
+    ffi.check(lib.td_profile_reset())
+    for _ in range(reps):
+        wl.step()
+    out = {}
+    for name, k in ffi.TD_K.items():
+        ms = ctypes.c_double(0)
+        cnt = ctypes.c_int64(0)
+        ffi.check(lib.td_profile_get(k, ctypes.byref(ms), ctypes.byref(cnt)))
+        if cnt.value:
+            out[name] = {"total_ms": ms.value / reps, "launches": cnt.value // reps,
+                         "avg_us": 1e3 * ms.value / cnt.value}
+    ffi.check(lib.td_profile_enable(0))
+    return out
+
+
+def cpu_baseline(kind, n_gpu, seconds):
+    """The oracle's exact solver (a single-thread C port of the path: cost build / generate +
+    exact assignment) timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import oracle
+    t_budget = time.perf_counter() + seconds
+    n = n_gpu
+    if kind != "g1":
+        n = min(n_gpu, 2048)
+    else:
+        n = min(n_gpu, 16384)
+    rng = np.random.default_rng(1)
+    reps, spent, tot = 0, 0.0, None
+    while True:
+        t0 = time.perf_counter()
+        if kind == "g1":
+            c = oracle.gen_uniform(n, 1 + reps, 10, 40)
+        elif kind == "g2":
+            _, c = oracle.cost_build(rng.integers(0, 10 * n, n), rng.integers(0, 10 * n, n), None, 250000, -1)
+        else:
+            _, c = oracle.cost_build(rng.integers(0, 50, n), rng.integers(0, 50, max(1, int(0.363 * n))), None,
+                                     250000, 10)
+        tot = oracle.assign(c)[0]
+        spent += time.perf_counter() - t0
+        reps += 1
+        if time.perf_counter() + spent / reps > t_budget or reps >= 8:
+            break
+    return {"value": n * reps / spent, "unit": "assignments/s", "cores": 1, "kind": "port",
+            "sample": "%d x (%s instance N=%d: build + exact shortest-augmenting-path solve, oracle/td_oracle.c, "
+                      "gcc -O3, one thread), %.1f s" % (reps, kind, n, spent),
+            "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "last_total": int(tot)}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import taxidispatcher_amd as td
+    from taxidispatcher_amd import _ffi as ffi
+    td.init(local)
+    # run on torch's current stream so that torch events / synchronize bracket our kernels
+    ffi.check(ffi.lib().td_set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    wl = Workload(args.workload, args.n, 1 + rank, torch, td, ffi)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total = wl.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    stats = td.last_stats()
+
+    prof = kernel_profile(wl, ffi, reps=3) if rank == 0 else {}
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    n = args.n
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * n * args.steps / dt
+    # dominant kernel class of a step, by device time
+    dom = max(prof, key=lambda k: prof[k]["total_ms"]) if prof else None
+    alg_bytes = {"gen": 4.0 * n * n, "cost_build": 4.0 * n * n, "compress": 4.0 * n * n,
+                 "bid": None, "sap": None, "assign": None, "final": None, "lcm": 4.0 * n * n}
+    roof = None
+    if dom:
+        p = prof[dom]
+        b = alg_bytes.get(dom)
+        if b is None:
+            # the solve as a whole must read every cost once: 4 N^2 algorithmic bytes, spread over
+            # the launches of this class
+            b = 4.0 * n * n / max(1, p["launches"])
+        achieved = b / (p["avg_us"] * 1e-6) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": b, "avg_launch_us": p["avg_us"], "launches_per_step": p["launches"]}
+    line = {
+        "metric": "NxN assignments/sec", "value": value, "unit": "assignments/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "%s N=%d: device cost write (4N^2 B) + exact assignment, total checked == optimum"
+                               % (args.workload, n), "n": n, "instances_per_step": world,
+                   "parallelism": "independent instance per GPU, no collective" if world > 1 else "single GPU"},
+        "pairs_per_s": world * float(n) * n * args.steps / dt,
+        "whole_step_algorithmic_GBps": 8.0 * n * n * world * args.steps / dt / 1e9,
+        "total_cost": int(total), "solver_stats": stats, "kernels": prof, "roofline": roof,
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.workload, n, args.cpu_seconds)
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

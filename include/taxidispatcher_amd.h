@@ -1,0 +1,135 @@
+/*
+ * taxidispatcher_amd.h — C ABI of the MI355X (gfx950) cab<->request assignment path.
+ *
+ * This is the drop-in boundary for ONE hot path of boguszjelinski/taxidispatcher:
+ *     cost-matrix build  ->  (optional) LCM greedy pre-reduce  ->  optimal N x N assignment
+ * i.e. what the reference hands to cvxopt.glpk.ilp.  Nothing native exists in the reference
+ * for this path (its three C files are pool finders), so each entry point cites the
+ * reference *function* it replaces; the Python binding a maintainer would add is shown in
+ * INTEGRATION.md and shipped in taxidispatcher_amd/_ffi.py.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; `void*` stream is a hipStream_t.
+ *   - every data pointer may be a HOST pointer or a DEVICE pointer of the active device;
+ *     the library detects which (hipPointerGetAttributes) and stages host buffers itself.
+ *   - caller owns every buffer; the library keeps no pointer past return.
+ *   - return 0 on success, a negative TD_E* code on failure; td_last_error() gives the text.
+ *     No exceptions cross the ABI.
+ *   - single-threaded like the reference (one solve at a time per process); calls are
+ *     synchronous unless the name ends in _async.
+ *   - cost matrices are row-major int32, row = cab (supply), column = request (demand),
+ *     exactly the reference's `cost[cab][cust]` / linear index n*cab+cust
+ *     (solver.py:13, greedy_opt.py:22-24, Simulator.java:378-380).
+ */
+#ifndef TAXIDISPATCHER_AMD_H
+#define TAXIDISPATCHER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define TD_API __attribute__((visibility("default")))
+#else
+#define TD_API
+#endif
+
+#define TD_OK 0
+#define TD_EINVAL (-1)   /* bad argument */
+#define TD_EHIP (-2)     /* a HIP runtime call failed */
+#define TD_ENOINIT (-3)  /* td_init not called */
+#define TD_ERANGE (-4)   /* cost range would overflow the solver's integer arithmetic */
+#define TD_EINTERNAL (-5)
+
+/* ---- life cycle -------------------------------------------------------------------- */
+TD_API int td_init(int device);            /* select GPU, create stream + workspace */
+TD_API void td_shutdown(void);
+TD_API const char *td_last_error(void);
+TD_API int td_set_stream(void *hip_stream); /* run on the caller's stream (NULL -> library stream) */
+TD_API int td_synchronize(void);
+TD_API int td_version(void);
+
+/* ---- a-2 cost-matrix build ---------------------------------------------------------
+ * Replaces calculate_cost: greedy_opt.py:86-99 (fill=big_cost, threshold<0),
+ * simulate.py:17-33 (threshold=DROP_TIME), Simulator.java:493-520 (same + id != -1, pass
+ * ids as NULL when all valid), and — with ids — procedure.py:6-12 (cells addressed by id,
+ * fill = n*n).
+ *   n = max(n_s, n_d);  cost is n*n int32, pre-filled with `fill`;
+ *   cost[c][d] = dist[cab_to[c]*S + dem_from[d]]   (dist == NULL  =>  |cab_to[c]-dem_from[d]|)
+ *   written only when threshold < 0 or value < threshold.
+ *   cab_id / dem_id: NULL => positional.  Non-NULL => a pair is skipped when either id is -1
+ *   (Simulator.java:508); with by_id != 0 the cell written is cost[cab_id[c]][dem_id[d]]
+ *   (procedure.py:12).
+ * One GPU thread per (cab, request) pair quad; position arrays read coalesced.
+ */
+TD_API int td_cost_build(const int32_t *cab_to, const int32_t *cab_id, int n_s,
+                  const int32_t *dem_from, const int32_t *dem_id, int n_d,
+                  const int32_t *dist, int S, int32_t fill, int32_t threshold, int by_id,
+                  int32_t *cost /* n*n */);
+
+/* ---- a-4 optimal assignment --------------------------------------------------------
+ * Replaces solve(n, cost) at solver.py:11-27 (and the ilp call at procedure.py:27,
+ * greedy_opt.py:117, simulate.py:52, heuristic.py:37): min sum c[i][j] x[i][j], every row
+ * and column used exactly once.  Output is row_to_col[n] (x[n*i + row_to_col[i]] == 1);
+ * td_expand_x gives the reference's n*n 0/1 vector.
+ *   total       optimal objective (exact integer, equals GLPK's optimum)
+ *   dual_bound  may be NULL; else an LP-duality lower bound computed on the device from the
+ *               final prices: dual_bound == total certifies optimality.
+ */
+TD_API int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_t *total,
+              int64_t *dual_bound);
+
+/* n*n bytes of 0/1 in the reference's order i = n*cab + cust (solver.py:36-39) */
+TD_API int td_expand_x(int n, const int32_t *row_to_col, uint8_t *x);
+
+/* ---- a-5 LCM greedy pre-reduce -----------------------------------------------------
+ * Replaces LCM: greedy_opt.py:61-82, simulate.py:76-98, heuristic.py:24-33,
+ * Simulator.java:523-549.  Repeatedly takes the first minimum in row-major order and masks
+ * its row and column.
+ *   threshold >= 0 : stop before taking a cell  > threshold     (greedy_opt.py:68-69)
+ *   stop_value_on  : stop before taking a cell == stop_value, and cells >= stop_value are
+ *                    never candidates                              (Simulator.java:529-538)
+ *   stop_size >= 0 : stop after taking when n - pairs == stop_size (Simulator.java:544-545)
+ *   sum_below      : a taken cell is summed only if value < sum_below (greedy_opt.py:74)
+ *   max_pairs      : capacity of rows[] / cols[] (n is always enough)
+ * Outputs pairs in the order the reference takes them.
+ */
+TD_API int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshold, int stop_value_on,
+           int32_t stop_value, int stop_size, int64_t sum_below, int max_pairs,
+           int32_t *rows, int32_t *cols, int32_t *n_pairs, int64_t *total, int32_t *last_min);
+
+/* ---- a-7 objective evaluation  (greedy_opt.py:21-29 count_sum) ---------------------- */
+TD_API int td_count_sum(int n, const int32_t *cost, const int32_t *row_to_col, int64_t big_cost,
+                 int64_t *sum, int32_t *n_real);
+
+/* ---- a-10 synthetic instances (bench / tests) --------------------------------------
+ * perf.jl:5  t = rand(lo:hi, n, n)  as a counter-based hash so that host oracle, one GPU
+ * and each row shard generate identical cells: cell(i,j) = lo + mulhi32(hi32(splitmix64(
+ * seed*0x100000001B3 + i*n + j)), hi-lo+1).  Writes rows [row0, row0+nrows).
+ */
+TD_API int td_gen_uniform(int n, uint64_t seed, int32_t lo, int32_t hi, int row0, int nrows,
+                   int32_t *cost /* nrows*n */);
+
+/* ---- profiling hooks used by bench.py ---------------------------------------------- */
+#define TD_K_COST_BUILD 0
+#define TD_K_GEN 1
+#define TD_K_COMPRESS 2
+#define TD_K_BID 3
+#define TD_K_ASSIGN 4
+#define TD_K_SAP 5
+#define TD_K_FINAL 6
+#define TD_K_LCM 7
+#define TD_K_COUNT 8
+TD_API int td_profile_enable(int on);                      /* HIP-event timing per kernel class */
+TD_API int td_profile_get(int kernel, double *total_ms, int64_t *launches);
+TD_API int td_profile_reset(void);
+/* counters of the last td_assign: [0]=bid rounds, [1]=row scans in bid rounds,
+ * [2]=free rows handed to SAP, [3]=SAP dijkstra steps, [4]=cost storage bytes per cell */
+TD_API int td_last_stats(int64_t *out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,43 @@
+"""Builds the gfx950 shared library in-tree: taxidispatcher_amd/libtaxidispatcher_amd.so.
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only container too.
+The .so is git-ignored but travels with the repo snapshot to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = [os.path.join(HERE, "csrc", f) for f in ("td_core.hip", "td_assign.hip", "td_lcm.hip", "td_shard.hip")]
+HDR = [os.path.join(HERE, "csrc", "td_common.h"), os.path.join(ROOT, "include", "taxidispatcher_amd.h")]
+LIB = os.path.join(HERE, "libtaxidispatcher_amd.so")
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in SRC + HDR)
+
+
+def build(force=False, verbose=False):
+    srcs = [f for f in SRC if os.path.exists(f)]
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
+           "-DTD_BUILDING=1", "-o", LIB] + srcs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,83 @@
+// td_common.h — shared host-side context for the gfx950 assignment library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+
+#include "taxidispatcher_amd.h"
+
+namespace td {
+
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Ctx {
+    bool inited = false;
+    int device = -1;
+    int n_cu = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    // grow-only device workspace, reused across calls (no hipMalloc on the hot path)
+    Buf stage_a, stage_b, stage_c, stage_d, stage_out;  // host<->device staging
+    Buf cc;                                             // compressed working copy of the cost matrix
+    Buf price, owner, r2c, bid, pred, rowmin, misc, list;
+    Buf lcm_a, lcm_b, lcm_c, lcm_d;
+    void *pinned = nullptr;  // small pinned host block for result read-back
+    size_t pinned_cap = 0;
+    // profiling
+    bool prof = false;
+    double prof_ms[TD_K_COUNT] = {0};
+    int64_t prof_n[TD_K_COUNT] = {0};
+    struct Pending {
+        hipEvent_t a, b;
+        int k;
+    };
+    Pending pend[4096];
+    int n_pend = 0;
+    hipEvent_t ev_pool[8192];
+    int n_ev = 0, ev_next = 0;
+    int64_t stats[8] = {0};
+};
+
+Ctx &ctx();
+int fail(int code, const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+int ensure(Buf &b, size_t bytes);
+bool is_device_ptr(const void *p);
+// returns a device pointer holding `bytes` of src (src itself when already on the device)
+int to_device(const void *src, size_t bytes, Buf &stage, const void **out);
+void prof_begin(int k);
+void prof_end(int k);
+void prof_flush();
+
+#define TD_HIP(call)                                       \
+    do {                                                   \
+        hipError_t _e = (call);                            \
+        if (_e != hipSuccess) return td::hip_fail(_e, #call); \
+    } while (0)
+
+#define TD_REQUIRE_INIT()                                                   \
+    do {                                                                    \
+        if (!td::ctx().inited) return td::fail(TD_ENOINIT, "td_init() has not been called"); \
+    } while (0)
+
+struct ProfScope {
+    int k;
+    explicit ProfScope(int k_) : k(k_) { prof_begin(k); }
+    ~ProfScope() { prof_end(k); }
+};
+
+__host__ __device__ inline uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+}  // namespace td

@@ -1,0 +1,201 @@
+// td_lcm.hip — LCM ("lowest cost method") greedy pre-reduce on gfx950.
+//
+// Reference: greedy_opt.py:61-82, simulate.py:76-98, heuristic.py:24-33, Simulator.java:523-549
+// — k times { global argmin in row-major order over the whole n x n matrix; mask row+col }.
+// The reference pays k full scans of n^2 cells.  Here the matrix is read ONCE:
+//   k_lcm_rowscan  segmented argmin: one wavefront per row keeps the row's first minimum
+//                  (value, col) as a packed 64-bit key (wave64 shuffle reduction);
+//   k_lcm_loop     one persistent workgroup repeats { block-wide argmin over the n row keys
+//                  (ties -> lowest row, then lowest col = the reference's row-major first
+//                  minimum); record the pair; mask; re-scan ONLY the rows whose cached column
+//                  was just taken } with the column mask as an LDS bitset.
+// Pairs come out in exactly the order the reference takes them.
+#include <limits.h>
+
+#include "td_common.h"
+
+using namespace td;
+
+namespace {
+
+constexpr unsigned long long LCM_INF = ~0ull;
+
+__device__ __forceinline__ unsigned long long lcm_key(int32_t v, int col)
+{
+    return ((unsigned long long)((uint32_t)v ^ 0x80000000u) << 32) | (uint32_t)col;
+}
+__device__ __forceinline__ int32_t lcm_val(unsigned long long k) { return (int32_t)((uint32_t)(k >> 32) ^ 0x80000000u); }
+
+// first minimum of one row among unmasked candidate columns, by one wavefront
+__device__ __forceinline__ unsigned long long lcm_scan_row(const int32_t *__restrict__ rp, int n, int lane,
+                                                           const uint32_t *colmask, int64_t cand_limit)
+{
+    unsigned long long best = LCM_INF;
+    for (int j = lane; j < n; j += 64) {
+        const int32_t v = rp[j];
+        const bool masked = colmask ? ((colmask[j >> 5] >> (j & 31)) & 1u) : false;
+        if (!masked && (int64_t)v < cand_limit) {
+            const unsigned long long k = lcm_key(v, j);
+            best = k < best ? k : best;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ob = __shfl_xor(best, o);
+        best = ob < best ? ob : best;
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(256) void k_lcm_rowscan(int n, const int32_t *__restrict__ cost, int64_t cand_limit,
+                                                     unsigned long long *__restrict__ rowbest)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int row = blockIdx.x * nw + w; row < n; row += gridDim.x * nw) {
+        const unsigned long long b = lcm_scan_row(cost + (int64_t)row * n, n, lane, nullptr, cand_limit);
+        if (lane == 0) rowbest[row] = b;
+    }
+}
+
+struct LcmOut {
+    int32_t n_pairs;
+    int32_t last_min;
+    int64_t total;
+};
+
+__global__ __launch_bounds__(1024) void k_lcm_loop(int n, const int32_t *__restrict__ cost, int64_t cand_limit,
+                                                   int32_t mask, int32_t threshold, int stop_value_on,
+                                                   int32_t stop_value, int stop_size, int64_t sum_below, int max_pairs,
+                                                   unsigned long long *__restrict__ rowbest, int32_t *__restrict__ rows,
+                                                   int32_t *__restrict__ cols, int *__restrict__ rescan,
+                                                   LcmOut *__restrict__ out)
+{
+    extern __shared__ uint32_t s_colmask[];  // (n+31)/32 words
+    __shared__ unsigned long long s_red[16];
+    __shared__ int s_nres;
+    const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
+    for (int k = tid; k < (n + 31) / 32; k += T) s_colmask[k] = 0u;
+    if (tid == 0) s_nres = 0;
+    __syncthreads();
+    int npairs = 0, size = n;
+    int32_t last_min = stop_value;
+    int64_t total = 0;
+    const int iters = n < max_pairs ? n : max_pairs;
+    for (int it = 0; it < iters; it++) {
+        // block argmin over (value, row); the column rides along in the row's cached key
+        unsigned long long best = LCM_INF;
+        for (int i = tid; i < n; i += T) {
+            const unsigned long long k = rowbest[i];
+            if (k != LCM_INF) {
+                const unsigned long long kk = (k & 0xFFFFFFFF00000000ull) | (uint32_t)i;
+                best = kk < best ? kk : best;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long ob = __shfl_xor(best, o);
+            best = ob < best ? ob : best;
+        }
+        if (lane == 0) s_red[w] = best;
+        __syncthreads();
+        best = s_red[0];
+        for (int k = 1; k < nw; k++) best = s_red[k] < best ? s_red[k] : best;
+        if (best == LCM_INF) {  // nothing left to look at
+            last_min = stop_value_on ? stop_value : mask;
+            break;
+        }
+        const int r = (int)(uint32_t)best;
+        const int32_t v = lcm_val(best);
+        const int c = (int)(uint32_t)rowbest[r];
+        last_min = v;
+        if (threshold >= 0 && v > threshold) break;       // greedy_opt.py:68-69
+        if (stop_value_on && v >= stop_value) break;       // Simulator.java:538
+        if (v >= mask) break;                              // only masked-valued cells remain
+        if (tid == 0) {
+            rows[npairs] = r;
+            cols[npairs] = c;
+        }
+        npairs++;
+        if ((int64_t)v < sum_below) total += v;
+        size--;
+        __syncthreads();  // everyone has read rowbest[r] / s_red
+        if (tid == 0) {
+            rowbest[r] = LCM_INF;
+            s_colmask[c >> 5] |= 1u << (c & 31);
+            s_nres = 0;
+        }
+        __syncthreads();
+        if (stop_size >= 0 && size == stop_size) break;    // Simulator.java:544-545
+        // rows whose cached first minimum sat in column c must be re-scanned
+        for (int i = tid; i < n; i += T) {
+            const unsigned long long k = rowbest[i];
+            if (k != LCM_INF && (int)(uint32_t)k == c) rescan[atomicAdd(&s_nres, 1)] = i;
+        }
+        __syncthreads();
+        const int nres = s_nres;
+        for (int q = w; q < nres; q += nw) {
+            const int i = rescan[q];
+            const unsigned long long b = lcm_scan_row(cost + (int64_t)i * n, n, lane, s_colmask, cand_limit);
+            if (lane == 0) rowbest[i] = b;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out->n_pairs = npairs;
+        out->last_min = last_min;
+        out->total = total;
+    }
+}
+
+}  // namespace
+
+extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshold, int stop_value_on,
+                      int32_t stop_value, int stop_size, int64_t sum_below, int max_pairs, int32_t *rows,
+                      int32_t *cols, int32_t *n_pairs, int64_t *total, int32_t *last_min)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (n < 0 || max_pairs < 0) return fail(TD_EINVAL, "negative size");
+    if (n_pairs) *n_pairs = 0;
+    if (total) *total = 0;
+    if (last_min) *last_min = stop_value;
+    if (n == 0) return TD_OK;
+    if (!cost || !rows || !cols) return fail(TD_EINVAL, "null array");
+    int rc;
+    const void *d_cost_v;
+    if ((rc = to_device(cost, sizeof(int32_t) * (size_t)n * n, c.stage_d, &d_cost_v))) return rc;
+    const int32_t *d_cost = (const int32_t *)d_cost_v;
+    if ((rc = ensure(c.lcm_a, sizeof(unsigned long long) * (size_t)n))) return rc;
+    if ((rc = ensure(c.lcm_b, sizeof(int32_t) * 2 * (size_t)n))) return rc;
+    if ((rc = ensure(c.lcm_c, sizeof(int32_t) * (size_t)n))) return rc;
+    if ((rc = ensure(c.lcm_d, 256))) return rc;
+    const int cap = std::min(n, max_pairs);
+    int32_t *d_rows = (int32_t *)c.lcm_b.p, *d_cols = d_rows + n;
+    // Java's scan only ever sees cells strictly below big_cost (Simulator.java:529-537)
+    const int64_t cand_limit = stop_value_on ? (int64_t)stop_value : (int64_t)INT64_MAX;
+    const size_t shm = sizeof(uint32_t) * (size_t)((n + 31) / 32);
+    {
+        ProfScope ps(TD_K_LCM);
+        k_lcm_rowscan<<<std::min((n + 3) / 4, c.n_cu * 8), 256, 0, c.stream>>>(n, d_cost, cand_limit,
+                                                                               (unsigned long long *)c.lcm_a.p);
+        int T = std::min(1024, std::max(64, ((n + 63) / 64) * 64));
+        k_lcm_loop<<<1, T, shm, c.stream>>>(n, d_cost, cand_limit, mask, threshold, stop_value_on, stop_value,
+                                            stop_size, sum_below, cap, (unsigned long long *)c.lcm_a.p, d_rows, d_cols,
+                                            (int *)c.lcm_c.p, (LcmOut *)c.lcm_d.p);
+    }
+    TD_HIP(hipGetLastError());
+    TD_HIP(hipMemcpyAsync(c.pinned, c.lcm_d.p, sizeof(LcmOut), hipMemcpyDeviceToHost, c.stream));
+    TD_HIP(hipStreamSynchronize(c.stream));
+    const LcmOut o = *(const LcmOut *)c.pinned;
+    if (o.n_pairs > 0) {
+        const hipMemcpyKind kr = is_device_ptr(rows) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        const hipMemcpyKind kc = is_device_ptr(cols) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        TD_HIP(hipMemcpyAsync(rows, d_rows, sizeof(int32_t) * (size_t)o.n_pairs, kr, c.stream));
+        TD_HIP(hipMemcpyAsync(cols, d_cols, sizeof(int32_t) * (size_t)o.n_pairs, kc, c.stream));
+        TD_HIP(hipStreamSynchronize(c.stream));
+    }
+    if (n_pairs) *n_pairs = o.n_pairs;
+    if (total) *total = o.total;
+    if (last_min) *last_min = o.last_min;
+    return TD_OK;
+}

@@ -1,0 +1,247 @@
+"""Host-side mirror of the reference's Python interface for the assignment hot path.
+
+Same function names, argument meaning and return shapes as the reference scripts, so a user
+of `procedure.py` / `greedy_opt.py` / `simulate.py` / `solver.py` can switch the import and keep
+the calling code.  Every function runs on the MI355X through the C ABI (`_ffi`); nothing here
+computes an assignment, a cost matrix or an LCM on the CPU.
+
+Reference map (file:line in boguszjelinski/taxidispatcher):
+    calculate_cost        greedy_opt.py:86-99, simulate.py:17-33 (drop_time), Simulator.java:493-520
+    calculate_cost_by_id  procedure.py:6-12
+    solve                 greedy_opt.py:102-118 / simulate.py:36-53  -> (n, x, cost)
+    procedure_solve       procedure.py:5-29                           -> x
+    solve_cost            solver.py:11-27                             -> x
+    LCM                   greedy_opt.py:61-82 / simulate.py:76-98
+    LCM_heuristic         heuristic.py:24-33
+    LCM_simulator         Simulator.java:523-549
+    count_sum             greedy_opt.py:21-29
+    filter_out            greedy_opt.py:32-37 (by id) / simulate.py:64-69 (by position)
+    combined              greedy_opt.py:136-160
+"""
+import ctypes
+
+import numpy as np
+
+from . import _ffi
+
+BIG_COST = 250000  # greedy_opt.py:5, simulate.py:12, Simulator.java:115
+
+
+# ----------------------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------------------
+def _records(rows):
+    """(id, from, to) iterables -> three int32 arrays."""
+    rows = list(rows)
+    if not rows:
+        z = np.zeros(0, np.int32)
+        return z, z, z
+    a = _ffi.as_i32(rows).reshape(len(rows), -1)
+    return np.ascontiguousarray(a[:, 0]), np.ascontiguousarray(a[:, 1]), np.ascontiguousarray(a[:, 2])
+
+
+def _dist_arg(distances):
+    """distances: None (=> |a-b|), an S x S array-like, or a (device_ptr, S) tuple."""
+    if distances is None:
+        return None, 0, None
+    if isinstance(distances, tuple):
+        return distances[0], int(distances[1]), None
+    if hasattr(distances, "data_ptr") and getattr(distances, "is_cuda", False):
+        return distances.data_ptr(), int(distances.shape[0]), distances
+    d = _ffi.as_i32(distances)
+    if d.ndim != 2 or d.shape[0] != d.shape[1]:
+        raise _ffi.TdError("distances must be a square S x S table")
+    return d.ctypes.data, int(d.shape[0]), d
+
+
+def cost_build(cab_to, dem_from, distances=None, fill=BIG_COST, threshold=-1, cab_id=None, dem_id=None,
+               by_id=False, out=None):
+    """Thin wrapper over td_cost_build. Returns (n, cost) with cost an int32 n x n numpy array,
+    or writes into `out` (numpy array or torch CUDA tensor) and returns (n, out)."""
+    lib = _ffi.lib()
+    cab_to = _ffi.as_i32(cab_to)
+    dem_from = _ffi.as_i32(dem_from)
+    n_s, n_d = int(cab_to.size), int(dem_from.size)
+    n = max(n_s, n_d)
+    cab_id = None if cab_id is None else _ffi.as_i32(cab_id)
+    dem_id = None if dem_id is None else _ffi.as_i32(dem_id)
+    dptr, S, keep = _dist_arg(distances)
+    if out is None:
+        out = np.empty((n, n), np.int32)
+    if n:
+        _ffi.check(lib.td_cost_build(_ffi.addr(cab_to), _ffi.addr(cab_id), n_s, _ffi.addr(dem_from),
+                                     _ffi.addr(dem_id), n_d, dptr, S, int(fill), int(threshold), int(bool(by_id)),
+                                     _ffi.addr(out)))
+    del keep
+    return n, out
+
+
+def assign(cost, n=None, want_dual=False):
+    """Thin wrapper over td_assign. cost: n x n int32 (numpy or torch CUDA tensor).
+    Returns (row_to_col int32[n], total[, dual_bound])."""
+    lib = _ffi.lib()
+    if isinstance(cost, np.ndarray) or not hasattr(cost, "data_ptr"):
+        cost = _ffi.as_i32(cost)
+    if n is None:
+        n = int(cost.shape[0])
+    r2c = np.empty(n, np.int32)
+    total = ctypes.c_int64(0)
+    dual = ctypes.c_int64(0)
+    _ffi.check(lib.td_assign(n, _ffi.addr(cost), _ffi.addr(r2c), ctypes.byref(total),
+                             ctypes.byref(dual) if want_dual else None))
+    if want_dual:
+        return r2c, int(total.value), int(dual.value)
+    return r2c, int(total.value)
+
+
+def expand_x(n, row_to_col):
+    """row_to_col -> the reference's n*n 0/1 vector, index n*cab + cust (solver.py:36-39)."""
+    x = np.zeros(n * n, np.uint8)
+    if n:
+        _ffi.check(_ffi.lib().td_expand_x(n, _ffi.addr(_ffi.as_i32(row_to_col)), _ffi.addr(x)))
+    return x
+
+
+def last_stats():
+    out = (ctypes.c_int64 * 8)()
+    _ffi.check(_ffi.lib().td_last_stats(out, 8))
+    return {"bid_rounds": out[0], "sap_free_rows": out[2], "sap_steps": out[3], "bytes_per_cell": out[4]}
+
+
+# ----------------------------------------------------------------------------------------
+# reference-shaped API
+# ----------------------------------------------------------------------------------------
+def calculate_cost(distances, demand, cabs, big_cost=BIG_COST, drop_time=None):
+    """greedy_opt.py:86-99. With drop_time (simulate.py:27: DROP_TIME=10) a cell is written only
+    if distance < drop_time. n == 0 -> (0, 0) as simulate.py:21."""
+    _, _, c_to = _records(cabs)
+    _, d_frm, _ = _records(demand)
+    if max(c_to.size, d_frm.size) == 0:
+        return 0, 0
+    return cost_build(c_to, d_frm, distances, fill=big_cost, threshold=-1 if drop_time is None else drop_time)
+
+
+def calculate_cost_by_id(distances, demand, cabs):
+    """procedure.py:6-12: fill n*n, cells addressed by the records' ids."""
+    c_id, _, c_to = _records(cabs)
+    d_id, d_frm, _ = _records(demand)
+    n = max(c_to.size, d_frm.size)
+    if n == 0:
+        return 0, np.zeros((0, 0), np.int32)
+    return cost_build(c_to, d_frm, distances, fill=n * n, threshold=-1, cab_id=c_id, dem_id=d_id, by_id=True)
+
+
+def solve_cost(n, cost):
+    """solver.py:11-27 solve(n, cost) -> x ; n == 0 -> (0, []) (solver.py:12)."""
+    if n == 0:
+        return 0, []
+    r2c, _ = assign(cost, n)
+    return expand_x(n, r2c)
+
+
+def procedure_solve(distances, demand, cabs):
+    """procedure.py:5-29 solve(distances, demand, cabs) -> x (length n*n, x[n*cab+cust] == 1)."""
+    n, cost = calculate_cost_by_id(distances, demand, cabs)
+    if n == 0:
+        return np.zeros(0, np.uint8)
+    r2c, _ = assign(cost, n)
+    return expand_x(n, r2c)
+
+
+def solve(distances, demand, cabs, big_cost=BIG_COST, drop_time=None):
+    """greedy_opt.py:102-118 / simulate.py:36-53 -> (n, x, cost); n == 0 -> (0, [], 0)."""
+    n, cost = calculate_cost(distances, demand, cabs, big_cost, drop_time)
+    if n == 0:
+        return 0, [], 0
+    r2c, _ = assign(cost, n)
+    return n, expand_x(n, r2c), cost
+
+
+def _lcm(n, c, mask, threshold, stop_value_on, stop_value, stop_size, sum_below):
+    lib = _ffi.lib()
+    if not hasattr(c, "data_ptr"):
+        c = _ffi.as_i32(c).reshape(n, n)
+    rows = np.empty(max(n, 1), np.int32)
+    cols = np.empty(max(n, 1), np.int32)
+    k = ctypes.c_int32(0)
+    tot = ctypes.c_int64(0)
+    lm = ctypes.c_int32(0)
+    _ffi.check(lib.td_lcm(n, _ffi.addr(c), int(mask), int(threshold), int(stop_value_on), int(stop_value),
+                          int(stop_size), int(sum_below), n, _ffi.addr(rows), _ffi.addr(cols), ctypes.byref(k),
+                          ctypes.byref(tot), ctypes.byref(lm)))
+    return int(tot.value), rows[:k.value].copy(), cols[:k.value].copy(), int(lm.value)
+
+
+def LCM(n, c, threshold=10, big_cost=BIG_COST, with_pairs=False):
+    """greedy_opt.py:61-82 (THRESHOLD=10) / simulate.py:76-98 (THRESHOLD=20, with_pairs=True).
+    `c` is the cab-major n x n cost (what np.array(matrix(cost).T) is in the reference).
+    Returns (total_cost, allocated_supply, allocated_demand[, allocated])."""
+    total, rows, cols, _ = _lcm(n, c, big_cost, threshold, 0, 0, -1, big_cost)
+    if with_pairs:
+        return total, list(map(int, rows)), list(map(int, cols)), list(zip(map(int, rows), map(int, cols)))
+    return total, list(map(int, rows)), list(map(int, cols))
+
+
+def LCM_heuristic(n, c):
+    """heuristic.py:24-33: n iterations, every taken cell summed, mask value 100."""
+    total, rows, cols, _ = _lcm(n, c, 100, -1, 0, 0, -1, 2**62)
+    return total, list(map(int, rows)), list(map(int, cols))
+
+
+def LCM_simulator(cost, max_non_lcm=600, big_cost=BIG_COST):
+    """Simulator.java:523-549 -> (pairs [(cab, request)], LCM_min_val)."""
+    cost_a = cost if hasattr(cost, "data_ptr") else _ffi.as_i32(cost)
+    n = int(cost_a.shape[0])
+    _, rows, cols, lm = _lcm(n, cost_a, big_cost, -1, 1, big_cost, max_non_lcm, big_cost)
+    return list(zip(map(int, rows), map(int, cols))), lm
+
+
+def count_sum(nn, cost, res, big_cost=BIG_COST):
+    """greedy_opt.py:21-29 with positional lists: because cost[taxi][trip] IS
+    dist[supply[taxi].to][demand[trip].from] for every real cell, the sum over x==1 cells with
+    cost < big_cost equals the reference's sum of dist[...] terms. `res` is x (n*n) or row_to_col."""
+    res = np.asarray(res)
+    if res.size == nn * nn and nn != 1:
+        r2c = np.full(nn, -1, np.int32)
+        ii, jj = np.nonzero(res.reshape(nn, nn) == 1)
+        r2c[ii] = jj
+    else:
+        r2c = _ffi.as_i32(res)
+    s = ctypes.c_int64(0)
+    k = ctypes.c_int32(0)
+    if not hasattr(cost, "data_ptr"):
+        cost = _ffi.as_i32(cost)
+    _ffi.check(_ffi.lib().td_count_sum(nn, _ffi.addr(cost), _ffi.addr(r2c), int(big_cost), ctypes.byref(s),
+                                       ctypes.byref(k)))
+    return int(s.value)
+
+
+def filter_out(input, allocated, element=None):
+    """element given: greedy_opt.py:32-37 (drop rows whose row[element] is in `allocated`);
+    element None: simulate.py:64-69 (drop by position). Host list bookkeeping, O(n)."""
+    alloc = set(int(a) for a in allocated)
+    if element is None:
+        output = [row for i, row in enumerate(input) if i not in alloc]
+    else:
+        output = [row for row in input if row[element] not in alloc]
+    return len(output), output
+
+
+def combined(distances, demand, cabs, threshold=10, big_cost=BIG_COST):
+    """greedy_opt.py:136-160: optimal solve, then LCM(threshold) + optimal on the remainder.
+    Returns (nn, res, n2, res2 + lcm) — the four numbers the reference appends to its log."""
+    nn, x, cost_table = solve(distances, demand, cabs, big_cost)
+    if nn == 0:
+        return 0, 0, 0, 0
+    res = count_sum(nn, cost_table, x, big_cost)
+    lcm, allocated_cabs, allocated_cust = LCM(nn, cost_table, threshold, big_cost)
+    # ids equal positions in rand_list (greedy_opt.py:47-50) but filter by the records' own id
+    cabs = list(cabs)
+    demand = list(demand)
+    cab_ids = [cabs[i][0] for i in allocated_cabs if i < len(cabs)]
+    cust_ids = [demand[i][0] for i in allocated_cust if i < len(demand)]
+    _, rest_demand = filter_out(demand, cust_ids, 0)
+    _, rest_cabs = filter_out(cabs, cab_ids, 0)
+    n2, x2, cost_table2 = solve(distances, rest_demand, rest_cabs, big_cost)
+    res2 = count_sum(n2, cost_table2, x2, big_cost) if n2 else 0
+    return nn, res, n2, res2 + lcm

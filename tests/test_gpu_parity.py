@@ -1,0 +1,306 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI
+(taxidispatcher_amd/_ffi.py -> libtaxidispatcher_amd.so) and is checked against the oracle.
+Integer work: bit-exact."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "known_answers.json")))
+BIG = 250000
+
+
+def make_instance(kind, n, rng):
+    if kind == "g1":      # perf.jl:5
+        return rng.integers(10, 41, (n, n)).astype(np.int32)
+    if kind == "g4":      # heuristic.py:21
+        return rng.integers(1, 40, (n, n)).astype(np.int32)
+    if kind == "wide":
+        return rng.integers(0, 1000000, (n, n)).astype(np.int32)
+    if kind == "neg":
+        return rng.integers(-5000, 5000, (n, n)).astype(np.int32)
+    if kind == "const":
+        return np.full((n, n), 7, np.int32)
+    S = 50 if kind == "g3" else 10 * n
+    a = rng.integers(0, S, n)
+    b = rng.integers(0, S, n)
+    c = np.abs(a[:, None] - b[None, :]).astype(np.int32)
+    if kind == "g3":      # Simulator.java:493-520 shape: threshold 10, dummy columns
+        nd = max(1, int(n * 0.363))
+        c[c >= 10] = BIG
+        c[:, nd:] = BIG
+    return c
+
+
+def check_assignment(td, c):
+    n = c.shape[0]
+    r2c, total, dual = td.assign(c, want_dual=True)
+    t_ref, r_ref, u, v = oracle.assign(c)
+    assert total == t_ref, "total differs from the optimum"
+    assert dual == total, "device LP-duality certificate does not close"
+    assert sorted(r2c.tolist()) == list(range(n))
+    assert int(c[np.arange(n), r2c].astype(np.int64).sum()) == total
+    if n <= 600 and oracle.is_unique(c, r_ref, u, v):
+        assert np.array_equal(r2c, r_ref), "unique optimum but per-cab assignment differs"
+    return r2c, total
+
+
+def test_known_answers(td):
+    for key in ("pdf_table5", "procedure_py"):
+        c = np.array(GOLD[key]["cost"], np.int32)
+        r2c, total = check_assignment(td, c)
+        assert total == GOLD[key]["total"]
+    c = np.array(GOLD["procedure_py"]["cost"], np.int32)
+    r2c, _ = td.assign(c)
+    assert r2c[0] == 2 and r2c[2] == 3  # forced in every optimum
+
+
+def test_procedure_py_api(td):
+    """procedure.py:32-57 end to end: same inputs, same printed pairs up to ties."""
+    g = GOLD["procedure_py"]
+    S = g["n_stands"]
+    dist = np.zeros((S, S))
+    for i in range(S):
+        for j in range(i, S):
+            dist[j][i] = j - i
+            dist[i][j] = dist[j][i]
+    demand = [tuple(r) for r in g["demand"]]
+    cabs = [tuple(r) for r in g["cabs"]]
+    x = td.procedure_solve(dist, demand, cabs)
+    n_cust = 4
+    assert len(x) == 16 and int(x.sum()) == 4
+    taken = [(dem, trip) for dem in range(3) for trip in range(n_cust) if x[n_cust * dem + trip] == 1]
+    assert len(taken) == 3 and (0, 2) in taken and (2, 3) in taken
+    n, cost = td.calculate_cost_by_id(dist, demand, cabs)
+    assert cost.tolist() == g["cost"]
+    real = sum(cost[c][d] for c, d in taken)
+    assert real == g["real_total"]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 15, 16, 17, 31, 63, 64, 65, 100, 127, 128, 129, 257, 400, 600, 1000])
+def test_assign_sizes(td, n):
+    rng = np.random.default_rng(1000 + n)
+    for kind in ("g1", "g4", "g2", "g3", "wide", "neg", "const"):
+        check_assignment(td, make_instance(kind, n, rng))
+
+
+@pytest.mark.parametrize("kind,n", [("g1", 1300), ("g3", 1300), ("g2", 1300), ("g1", 2048), ("wide", 2048),
+                                    ("g1", 4096), ("g3", 2500)])
+def test_assign_larger(td, kind, n):
+    rng = np.random.default_rng(n)
+    check_assignment(td, make_instance(kind, n, rng))
+
+
+def test_assign_unique_optimum_per_cab(td):
+    """Strictly dominant diagonal => unique optimum => per-cab parity is required."""
+    rng = np.random.default_rng(9)
+    for n in (8, 100, 513):
+        perm = rng.permutation(n)
+        c = rng.integers(50, 90, (n, n)).astype(np.int32)
+        c[np.arange(n), perm] = rng.integers(0, 5, n)
+        r2c, total = check_assignment(td, c)
+        t_ref, r_ref, u, v = oracle.assign(c)
+        assert oracle.is_unique(c, r_ref, u, v)
+        assert np.array_equal(r2c, perm) and np.array_equal(r_ref, perm)
+
+
+def test_assign_extreme_values(td):
+    rng = np.random.default_rng(4)
+    n = 40
+    c = rng.integers(0, 2**31 - 1, (n, n)).astype(np.int32)       # needs the u32 path
+    check_assignment(td, c)
+    c = rng.integers(-2**31, 2**31 - 1, (n, n)).astype(np.int32)
+    check_assignment(td, c)
+    c = rng.integers(0, 300, (n, n)).astype(np.int32)              # u16 path
+    check_assignment(td, c)
+    c = rng.integers(0, 70000, (n, n)).astype(np.int32)            # u32 path, moderate
+    check_assignment(td, c)
+    # row offsets far apart but narrow per-row range -> still the u8 path
+    c = (rng.integers(0, 200, (n, n)) + rng.integers(0, 10**9, (n, 1))).astype(np.int32)
+    check_assignment(td, c)
+    assert td.last_stats()["bytes_per_cell"] == 1
+
+
+def test_empty_and_device_pointers(td):
+    import torch
+    assert td.solve_cost(0, []) == (0, [])
+    assert td.calculate_cost(None, [], []) == (0, 0)
+    n = 300
+    c = oracle.gen_uniform(n, 3)
+    ct = torch.from_numpy(c).cuda()
+    r2c_t = torch.empty(n, dtype=torch.int32, device="cuda")
+    tot = ctypes.c_int64(0)
+    from taxidispatcher_amd import _ffi
+    _ffi.check(_ffi.lib().td_assign(n, ct.data_ptr(), r2c_t.data_ptr(), ctypes.byref(tot), None))
+    assert tot.value == oracle.assign(c)[0]
+    r = r2c_t.cpu().numpy()
+    assert sorted(r.tolist()) == list(range(n)) and int(c[np.arange(n), r].sum()) == tot.value
+
+
+def test_gen_uniform_bit_exact(td):
+    from taxidispatcher_amd import _ffi
+    for n, row0, nrows in [(8, 0, 8), (1000, 0, 1000), (1001, 5, 77), (64, 63, 1)]:
+        out = np.empty((nrows, n), np.int32)
+        _ffi.check(_ffi.lib().td_gen_uniform(n, 1, 10, 40, row0, nrows, out.ctypes.data))
+        assert np.array_equal(out, oracle.gen_uniform(n, 1, 10, 40, row0, nrows))
+    g = GOLD["gen_uniform_seed1_n8"]
+    out = np.empty((8, 8), np.int32)
+    _ffi.check(_ffi.lib().td_gen_uniform(8, 1, 10, 40, 0, 8, out.ctypes.data))
+    assert out[0].tolist() == g["first_row"] and int(out.sum()) == g["sum"]
+
+
+@pytest.mark.parametrize("n_s,n_d", [(1, 1), (3, 4), (13, 7), (7, 13), (64, 64), (600, 218), (257, 1001), (1300, 1300)])
+def test_cost_build_variants(td, n_s, n_d):
+    rng = np.random.default_rng(n_s * 7 + n_d)
+    for S in (50, 300):
+        cab_to = rng.integers(0, S, n_s)
+        dem_from = rng.integers(0, S, n_d)
+        dist = rng.integers(0, 60, (S, S)).astype(np.int32)   # a general (asymmetric) table
+        for d in (None, dist):
+            for thr in (-1, 10):
+                n, c = td.cost_build(cab_to, dem_from, d, fill=BIG, threshold=thr)
+                n_o, c_o = oracle.cost_build(cab_to, dem_from, d, BIG, thr)
+                assert n == n_o and np.array_equal(c, c_o)
+        cab_id = np.arange(n_s)
+        dem_id = np.arange(n_d)
+        cab_id[rng.integers(0, n_s)] = -1
+        dem_id[rng.integers(0, n_d)] = -1
+        n, c = td.cost_build(cab_to, dem_from, dist, fill=BIG, threshold=10, cab_id=cab_id, dem_id=dem_id)
+        n_o, c_o = oracle.cost_build(cab_to, dem_from, dist, BIG, 10, cab_id, dem_id)
+        assert np.array_equal(c, c_o)
+
+
+def test_reference_shaped_calculate_cost_and_solve(td):
+    """greedy_opt.py:86-118 / simulate.py:17-53 call shapes."""
+    rng = np.random.default_rng(12)
+    S = 4000
+    demand = [(i, int(rng.integers(0, S)), int(rng.integers(0, S))) for i in range(57)]
+    cabs = [(i, int(rng.integers(0, S)), int(rng.integers(0, S))) for i in range(60)]
+    n, cost = td.calculate_cost(None, demand, cabs)
+    assert n == 60 and cost[3][5] == abs(cabs[3][2] - demand[5][1]) and cost[0][59] == BIG
+    nn, x, cost_table = td.solve(None, demand, cabs)
+    assert nn == 60 and len(x) == 3600 and int(np.asarray(x).sum()) == 60
+    res = td.count_sum(nn, cost_table, x)
+    t_ref, r_ref, _, _ = oracle.assign(cost_table)
+    assert res == oracle.count_sum(cost_table, r_ref)[0]
+    # simulate.py variant with DROP_TIME on a 50-stand world
+    S = 50
+    dist = np.abs(np.arange(S)[:, None] - np.arange(S)[None, :])
+    demand = [(i, int(rng.integers(0, S)), int(rng.integers(0, S))) for i in range(30)]
+    cabs = [(i, int(rng.integers(0, S)), int(rng.integers(0, S))) for i in range(45)]
+    nn, x, cost_table = td.solve(dist, demand, cabs, drop_time=10)
+    _, c_o = oracle.cost_build([c[2] for c in cabs], [d[1] for d in demand], dist, BIG, 10)
+    assert np.array_equal(cost_table, c_o)
+    r2c = np.asarray(x).reshape(nn, nn).argmax(1)
+    assert int(c_o[np.arange(nn), r2c].sum()) == oracle.assign(c_o)[0]
+    assert td.solve(dist, [], [], drop_time=10) == (0, [], 0)
+
+
+@pytest.mark.parametrize("n", [1, 5, 17, 64, 100, 400, 1300])
+def test_lcm_variants(td, n):
+    rng = np.random.default_rng(77 + n)
+    # greedy_opt.py:61-82, threshold 10
+    c = rng.integers(0, 30, (n, n)).astype(np.int32)
+    tot, rows, cols = td.LCM(n, c, threshold=10)
+    t_o, r_o, c_o, _ = oracle.lcm(c, mask=BIG, threshold=10, sum_below=BIG)
+    assert (tot, rows, cols) == (t_o, r_o.tolist(), c_o.tolist())
+    # simulate.py:76-98, threshold 20, pair list
+    tot, rows, cols, pairs = td.LCM(n, c, threshold=20, with_pairs=True)
+    t_o, r_o, c_o, _ = oracle.lcm(c, mask=BIG, threshold=20, sum_below=BIG)
+    assert (tot, pairs) == (t_o, list(zip(r_o.tolist(), c_o.tolist())))
+    # heuristic.py:24-33
+    c = rng.integers(1, 40, (n, n)).astype(np.int32)
+    tot, rows, cols = td.LCM_heuristic(n, c)
+    t_o, r_o, c_o, _ = oracle.lcm(c, mask=100, threshold=-1)
+    assert (tot, rows, cols) == (t_o, r_o.tolist(), c_o.tolist())
+    # Simulator.java:523-549 on a thresholded tick-like matrix
+    a = rng.integers(0, 50, n)
+    b = rng.integers(0, 50, n)
+    c = np.abs(a[:, None] - b[None, :]).astype(np.int32)
+    c[c >= 10] = BIG
+    c[:, max(1, int(0.7 * n)):] = BIG
+    stop = max(0, n - max(1, n // 3))
+    pairs, lm = td.LCM_simulator(c, max_non_lcm=stop)
+    _, r_o, c_o, lm_o = oracle.lcm(c, mask=BIG, stop_value_on=1, stop_value=BIG, stop_size=stop, sum_below=BIG,
+                                   java_scan=1)
+    assert pairs == list(zip(r_o.tolist(), c_o.tolist())) and lm == lm_o
+    # exhausted: every real cell consumed -> LCM_min_val == big_cost (Simulator.java:188)
+    pairs, lm = td.LCM_simulator(c, max_non_lcm=-1)
+    _, r_o, c_o, lm_o = oracle.lcm(c, mask=BIG, stop_value_on=1, stop_value=BIG, stop_size=-1, sum_below=BIG,
+                                   java_scan=1)
+    assert pairs == list(zip(r_o.tolist(), c_o.tolist())) and lm == lm_o
+
+
+def test_combined_pipeline(td):
+    """greedy_opt.py:136-160 (a-8): n, opt, n2, opt2+lcm."""
+    rng = np.random.default_rng(5)
+    S, n0 = 4000, 400
+
+    def rand_list():
+        out, count = [], 0
+        for _ in range(n0):
+            frm, to = int(rng.integers(0, S)), int(rng.integers(0, S))
+            if frm != to:
+                out.append((count, frm, to))
+                count += 1
+        return out
+    demand, cabs = rand_list(), rand_list()
+    nn, res, n2, res2 = td.combined(None, demand, cabs, threshold=10)
+    n_o, cost = oracle.cost_build([c[2] for c in cabs], [d[1] for d in demand], None, BIG)
+    t, r, _, _ = oracle.assign(cost)
+    opt = oracle.count_sum(cost, r)[0]
+    lcm, rows, cols, _ = oracle.lcm(cost, mask=BIG, threshold=10, sum_below=BIG)
+    rest_c = np.delete(np.array([c[2] for c in cabs]), rows)
+    rest_d = np.delete(np.array([d[1] for d in demand]), cols)
+    n2_o, cost2 = oracle.cost_build(rest_c, rest_d, None, BIG)
+    t2, r2, _, _ = oracle.assign(cost2)
+    assert (nn, res, n2, res2) == (n_o, opt, n2_o, oracle.count_sum(cost2, r2)[0] + lcm)
+    assert res <= res2
+
+
+def test_solver_cli_roundtrip(td, tmp_path):
+    """cost.txt -> python -m taxidispatcher_amd.solver -> solv_out.txt (Simulator.java:195-207)."""
+    from taxidispatcher_amd import solver
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 50, 40)
+    b = rng.integers(0, 50, 25)
+    n, cost = oracle.cost_build(a, b, None, BIG, 10)
+    solver.write_cost(str(tmp_path / "cost.txt"), cost)
+    assert solver.main([str(tmp_path / "cost.txt"), str(tmp_path / "solv_out.txt")]) == 0
+    x = solver.read_solution(str(tmp_path / "solv_out.txt"), n)
+    xm = x.reshape(n, n)
+    assert (xm.sum(0) == 1).all() and (xm.sum(1) == 1).all()
+    assert int((xm * cost).sum()) == oracle.assign(cost)[0]
+    # OPT count is tie-invariant (Simulator.java:378-383)
+    t, r, _, _ = oracle.assign(cost)
+    assert int(((xm == 1) & (cost < BIG)).sum()) == oracle.count_sum(cost, r)[1]
+
+
+def test_large_properties(td):
+    """BASELINE sizes through size-independent properties: known optimum 10*N for the perf.jl
+    distribution (row-minimum bound), closed-form sorted matching for 1-D geometry, and the
+    device certificate."""
+    import torch
+    from taxidispatcher_amd import _ffi
+    n = 16384
+    cost = torch.empty((n, n), dtype=torch.int32, device="cuda")
+    _ffi.check(_ffi.lib().td_gen_uniform(n, 1, 10, 40, 0, n, cost.data_ptr()))
+    r2c, total, dual = td.assign(cost, n, want_dual=True)
+    assert total == 10 * n == dual
+    assert sorted(r2c.tolist()) == list(range(n))
+    picked = cost[torch.arange(n, device="cuda"), torch.from_numpy(r2c.astype(np.int64)).cuda()]
+    assert int(picked.sum().item()) == total and int(picked.max().item()) == 10
+    del cost
+    rng = np.random.default_rng(3)
+    n = 4096
+    a = rng.integers(0, 10 * n, n)
+    b = rng.integers(0, 10 * n, n)
+    ct = torch.empty((n, n), dtype=torch.int32, device="cuda")
+    td.cost_build(a, b, None, fill=BIG, threshold=-1, out=ct)
+    r2c, total, dual = td.assign(ct, n, want_dual=True)
+    assert total == int(np.abs(np.sort(a) - np.sort(b)).sum()) == dual
