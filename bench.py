@@ -136,12 +136,33 @@ def cpu_baseline(kind, n_gpu, seconds):
         tot = oracle.assign(c)[0]
         spent += time.perf_counter() - t0
         reps += 1
-        if time.perf_counter() + spent / reps > t_budget or reps >= 8:
+        if time.perf_counter() + spent / reps > t_budget or reps >= 64:
             break
     return {"value": n * reps / spent, "unit": "assignments/s", "cores": 1, "kind": "port",
             "sample": "%d x (%s instance N=%d: build + exact shortest-augmenting-path solve, oracle/td_oracle.c, "
                       "gcc -O3, one thread), %.1f s" % (reps, kind, n, spent),
             "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "last_total": int(tot)}
+
+
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
+    (profiles/*/rocprof_summary*.json, made by tools/profile_round.sh: separate FETCH_SIZE and
+    WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md). None if no summary exists."""
+    import glob
+    prefix = {"compress": "k_compress", "gen": "k_gen_uniform", "cost_build": "k_cost_build", "bid": "k_bid",
+              "sap": "k_sap", "assign": "k_assign", "final": "k_final", "lcm": "k_lcm"}.get(kernel_class)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "rocprof_summary*.json")), key=os.path.getmtime)
+    if not files or not prefix:
+        return None
+    try:
+        t = json.load(open(files[-1])).get("traffic_per_dispatch", {})
+        best = None
+        for k, v in t.items():
+            if prefix in k:
+                best = max(best or 0.0, float(v["hbm_bytes_corrected"]))
+        return best
+    except Exception:
+        return None
 
 
 def cpu_model():
@@ -216,7 +237,7 @@ def main():
             b = 4.0 * n * n / max(1, p["launches"])
         achieved = b / (p["avg_us"] * 1e-6) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
                 "algorithmic_bytes_per_launch": b, "avg_launch_us": p["avg_us"], "launches_per_step": p["launches"]}
     line = {
         "metric": "NxN assignments/sec", "value": value, "unit": "assignments/s", "n_gpus": world,

@@ -31,6 +31,7 @@
 // rounds and 10^2..10^4 in-kernel steps for the same instances and are exact by construction
 // (no (N+1) cost scaling needed).  See DESIGN.md.
 #include <limits.h>
+#include <stdlib.h>
 
 #include "td_common.h"
 
@@ -76,10 +77,22 @@ enum {
     CTL_STEPS = 3,     // SAP dijkstra steps
     CTL_ROUNDS = 4,    // bidding rounds that placed at least one bid
     CTL_PROG = 8,      // [CTL_PROG + r] bids applied in round r
-    CTL_WORDS = 8 + 64
+    CTL_WORDS = 8 + 64  // room for up to 48 rounds
 };
 
 constexpr int ROW_BITS = 20;
+
+// tunables (env TD_MAX_ROUNDS / TD_TIE_EVICT / TD_LDS_ROUNDS, read once at td_assign)
+int g_max_rounds = 16, g_tie_evict = 1, g_lds_rounds = 1;
+void read_tunables()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    if (const char *e = getenv("TD_MAX_ROUNDS")) g_max_rounds = std::max(1, std::min(48, atoi(e)));
+    if (const char *e = getenv("TD_TIE_EVICT")) g_tie_evict = atoi(e) != 0;
+    if (const char *e = getenv("TD_LDS_ROUNDS")) g_lds_rounds = std::max(0, atoi(e));
+}
 
 // ---- unpack one 16-byte chunk into E cost values -----------------------------------
 template <typename CT>
@@ -208,6 +221,79 @@ __global__ __launch_bounds__(256) void k_compress(int n, int nchunks, const int3
     }
 }
 
+// Register-resident variant: the row is read ONCE from HBM (all VPT 16-byte loads of a thread
+// are issued back to back, so a 256-thread workgroup keeps 64 KiB in flight), reduced, and
+// written back narrow.  Needs n % 4 == 0, a 16-byte aligned matrix and n/4 <= THREADS*VPT.
+template <typename CT, int VPT, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nchunks, const int32_t *__restrict__ cost,
+                                                          CT *__restrict__ cc, int32_t *__restrict__ rowmin,
+                                                          int *__restrict__ ctl)
+{
+    constexpr int E = Tr<CT>::E;
+    constexpr int NW = THREADS / 64;
+    __shared__ int s_mn[2][NW], s_mx[2][NW];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const size_t pitch = (size_t)nchunks * E;
+    const int nq = n >> 2;
+    int par = 0;
+    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+        const int4 *s4 = reinterpret_cast<const int4 *>(cost + (int64_t)row * n);
+        int4 v[VPT];
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+            const int q = k * THREADS + tid;
+            if (q < nq) v[k] = s4[q];
+        }
+        int mn = INT_MAX, mx = INT_MIN;
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+            const int q = k * THREADS + tid;
+            if (q < nq) {
+                mn = min(min(mn, v[k].x), min(v[k].y, min(v[k].z, v[k].w)));
+                mx = max(max(mx, v[k].x), max(v[k].y, max(v[k].z, v[k].w)));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn = min(mn, __shfl_xor(mn, o));
+            mx = max(mx, __shfl_xor(mx, o));
+        }
+        if (lane == 0) {
+            s_mn[par][w] = mn;
+            s_mx[par][w] = mx;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            mn = min(mn, s_mn[par][k]);
+            mx = max(mx, s_mx[par][k]);
+        }
+        par ^= 1;
+        if (tid == 0) {
+            rowmin[row] = mn;
+            if ((int64_t)mx - (int64_t)mn > Tr<CT>::LIMIT) atomicOr(&ctl[CTL_FLAG], 1);
+        }
+        CT *dst = cc + (size_t)row * pitch;
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+            const int q = k * THREADS + tid;
+            if (q < nq) {
+                const uint32_t a = (uint32_t)(v[k].x - mn), b = (uint32_t)(v[k].y - mn), c = (uint32_t)(v[k].z - mn),
+                               d = (uint32_t)(v[k].w - mn);
+                if constexpr (sizeof(CT) == 1) {
+                    reinterpret_cast<uint32_t *>(dst)[q] = (a & 0xFF) | ((b & 0xFF) << 8) | ((c & 0xFF) << 16) | (d << 24);
+                } else if constexpr (sizeof(CT) == 2) {
+                    reinterpret_cast<uint2 *>(dst)[q] = make_uint2((a & 0xFFFF) | (b << 16), (c & 0xFFFF) | (d << 16));
+                } else {
+                    reinterpret_cast<uint4 *>(dst)[q] = make_uint4(a, b, c, d);
+                }
+            }
+        }
+        // sentinel tail up to the 16-byte chunk boundary
+        for (int j = n + tid; j < (int)pitch; j += THREADS) dst[j] = (CT)Tr<CT>::SENT;
+    }
+}
+
 // =====================================================================================
 // state init
 // =====================================================================================
@@ -233,10 +319,11 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nchunks, c
                                                           const typename Tr<CT>::PT *__restrict__ pk,
                                                           const int *__restrict__ r2c,
                                                           unsigned long long *__restrict__ bid,
-                                                          const int *__restrict__ ctl, int round)
+                                                          const int *__restrict__ ctl, int round, int tie_evict)
 {
     using PT = typename Tr<CT>::PT;
     constexpr int E = Tr<CT>::E;
+    constexpr int U = 4;  // 16-byte row chunks in flight per lane
     extern __shared__ __align__(16) unsigned char smem[];
     if (round > 0 && ctl[CTL_PROG + round - 1] == 0) return;  // previous round placed no bid: converged
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -252,39 +339,55 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nchunks, c
     for (int row = blockIdx.x * nw + w; row < n; row += gridDim.x * nw) {
         if (r2c[row] >= 0) continue;
         const CT *rp = cc + (size_t)row * pitch;
-        // start chunk of the rotated scan: spreads tie-breaks of different rows over the columns
-        const int rot = (int)(((uint64_t)((uint32_t)row * 0x9E3779B1u) * (uint64_t)nchunks) >> 32);
+        // Start chunk of the rotated scan.  It spreads the tie-breaks of different rows over the
+        // columns (with first-index tie-breaking every row of a perf.jl instance would bid for the
+        // same few columns) and changes every round, so an evicted row does not walk back to the
+        // column it was just thrown out of.
+        const uint32_t hsh = ((uint32_t)row + 1u) * 0x9E3779B1u + (uint32_t)round * 0x85EBCA6Bu;
+        const int rot = (int)(((uint64_t)(hsh ^ (hsh >> 15)) * (uint64_t)nchunks) >> 32);
         PT k1 = Tr<CT>::KMAX, k2 = Tr<CT>::KMAX;
         int pos1 = 0;
-        for (int t = lane; t < nchunks; t += 64) {
-            int ch = t + rot;
-            if (ch >= nchunks) ch -= nchunks;
-            const uint4 cv = *reinterpret_cast<const uint4 *>(rp + (size_t)ch * E);
-            uint32_t c[E];
-            unpack<CT>(cv, c);
-            PT pv[E];
-            if (sizeof(PT) == 4) {
-                const int4 *pp = reinterpret_cast<const int4 *>(P + (size_t)ch * E);
+        for (int t0 = lane; t0 < nchunks; t0 += 64 * U) {
+            uint4 cv[U];
+            int chs[U];
 #pragma unroll
-                for (int q = 0; q < E / 4; q++) {
-                    int4 x = pp[q];
-                    pv[4 * q + 0] = x.x;
-                    pv[4 * q + 1] = x.y;
-                    pv[4 * q + 2] = x.z;
-                    pv[4 * q + 3] = x.w;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < E; e++) pv[e] = P[(size_t)ch * E + e];
+            for (int u = 0; u < U; u++) {
+                const int t = t0 + 64 * u;
+                int ch = t + rot;
+                if (ch >= nchunks) ch -= nchunks;
+                chs[u] = t < nchunks ? ch : -1;
+                if (t < nchunks) cv[u] = *reinterpret_cast<const uint4 *>(rp + (size_t)ch * E);
             }
 #pragma unroll
-            for (int e = 0; e < E; e++) {
-                const PT key = (PT)(2 * (PT)c[e]) + pv[e];  // 2*(cost+price) + owned
-                const bool lt = key < k1;
-                const PT mx = key > k1 ? key : k1;
-                k2 = k2 < mx ? k2 : mx;
-                pos1 = lt ? (t * E + e) : pos1;
-                k1 = lt ? key : k1;
+            for (int u = 0; u < U; u++) {
+                if (chs[u] < 0) continue;
+                const int t = t0 + 64 * u;
+                uint32_t c[E];
+                unpack<CT>(cv[u], c);
+                PT pv[E];
+                if constexpr (sizeof(PT) == 4) {
+                    const int4 *pp = reinterpret_cast<const int4 *>(P + (size_t)chs[u] * E);
+#pragma unroll
+                    for (int q = 0; q < E / 4; q++) {
+                        const int4 x = pp[q];
+                        pv[4 * q + 0] = x.x;
+                        pv[4 * q + 1] = x.y;
+                        pv[4 * q + 2] = x.z;
+                        pv[4 * q + 3] = x.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; e++) pv[e] = P[(size_t)chs[u] * E + e];
+                }
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const PT key = (PT)(2 * (PT)c[e]) + pv[e];  // 2*(cost+price) + owned
+                    const bool lt = key < k1;
+                    const PT mx = key > k1 ? key : k1;
+                    k2 = k2 < mx ? k2 : mx;
+                    pos1 = lt ? (t * E + e) : pos1;
+                    k1 = lt ? key : k1;
+                }
             }
         }
         // wave64 butterfly: lexicographic min of (key, rotated position)
@@ -313,7 +416,10 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nchunks, c
             const int j1 = ch * E + (bp - t1 * E);
             const PT inc = (x == Tr<CT>::KMAX) ? (PT)0 : (PT)((x >> 1) - (bk >> 1));
             const bool owned = (bk & 1) != 0;
-            if (j1 < n && !(owned && inc == 0)) {
+            // A tie on an owned column raises no price.  With tie_evict the row still takes the
+            // column (complementary slackness stays exact, the previous owner re-bids next round
+            // and usually finds a free tied column); otherwise it is left to the finisher.
+            if (j1 < n && (!(owned && inc == 0) || tie_evict)) {
                 const PT newp = (P[j1] >> 1) + inc;
                 atomicMax(&bid[j1], ((unsigned long long)newp << ROW_BITS) | (unsigned long long)(row + 1));
             }
@@ -733,7 +839,20 @@ int run_compress(const Plan &pl, bool *fits)
     const int grid = std::min(pl.n, c.n_cu * 8);
     {
         ProfScope ps(TD_K_COMPRESS);
-        if (vec)
+        const int nq = pl.n / 4;
+        if (vec && nq <= 256 * 16) {
+            const int g2 = std::min(pl.n, c.n_cu * 4);
+#define TD_CR(VPT) k_compress_reg<CT, VPT, 256><<<g2, 256, 0, c.stream>>>(pl.n, nchunks, pl.d_cost, (CT *)c.cc.p, (int32_t *)c.rowmin.p, ctl)
+            if (nq <= 256) TD_CR(1);
+            else if (nq <= 512) TD_CR(2);
+            else if (nq <= 1024) TD_CR(4);
+            else if (nq <= 2048) TD_CR(8);
+            else TD_CR(16);
+#undef TD_CR
+        } else if (vec && nq <= 1024 * 16) {
+            k_compress_reg<CT, 16, 1024><<<std::min(pl.n, c.n_cu * 2), 1024, 0, c.stream>>>(pl.n, nchunks, pl.d_cost, (CT *)c.cc.p,
+                                                                                            (int32_t *)c.rowmin.p, ctl);
+        } else if (vec)
             k_compress<CT, true><<<grid, 256, 0, c.stream>>>(pl.n, nchunks, pl.d_cost, (CT *)c.cc.p, (int32_t *)c.rowmin.p, ctl);
         else
             k_compress<CT, false><<<grid, 256, 0, c.stream>>>(pl.n, nchunks, pl.d_cost, (CT *)c.cc.p, (int32_t *)c.rowmin.p, ctl);
@@ -775,21 +894,22 @@ int run_solve(const Plan &pl, int64_t *total, int64_t *dual)
     TD_HIP(hipMemsetAsync(out, 0, 16, c.stream));
 
     // ---- Jacobi bidding rounds -------------------------------------------------------
-    const int max_rounds = 16;
+    const int max_rounds = g_max_rounds;
     const size_t lds_prices = (size_t)npad * sizeof(PT);
     const bool can_lds = lds_prices <= 128 * 1024 && n >= 2048;
     if (can_lds && lds_prices > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)k_bid<CT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prices);
     for (int r = 0; r < max_rounds; r++) {
+        const int tie_evict = (r >= 1) ? g_tie_evict : 0;
         {
             ProfScope ps(TD_K_BID);
-            if (can_lds && r < 2) {
+            if (can_lds && r < g_lds_rounds) {
                 const int grid = std::min((n + 15) / 16, c.n_cu);
                 k_bid<CT, true><<<grid, 1024, lds_prices, c.stream>>>(n, nchunks, (const CT *)c.cc.p, pk, (const int *)c.r2c.p,
-                                                                      (unsigned long long *)c.bid.p, ctl, r);
+                                                                      (unsigned long long *)c.bid.p, ctl, r, tie_evict);
             } else {
                 k_bid<CT, false><<<(n + 3) / 4, 256, 0, c.stream>>>(n, nchunks, (const CT *)c.cc.p, pk, (const int *)c.r2c.p,
-                                                                    (unsigned long long *)c.bid.p, ctl, r);
+                                                                    (unsigned long long *)c.bid.p, ctl, r, tie_evict);
             }
         }
         {
@@ -864,6 +984,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
 {
     TD_REQUIRE_INIT();
     Ctx &c = ctx();
+    read_tunables();
     if (n < 0) return fail(TD_EINVAL, "n < 0");
     if (n == 0) {  // solver.py:12  "if n==0: return 0, []"
         if (total) *total = 0;
