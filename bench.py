@@ -40,6 +40,11 @@ def parse():
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--workload", default="g1", choices=["g1", "g2", "g3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the sharded leg even with one rank (exercises RCCL + the shard API on 1 GPU)")
+    ap.add_argument("--sharded-n", type=int, default=65536,
+                    help="with --gpus > 1: also solve ONE instance of this size row-sharded over all ranks "
+                         "(BASELINE configs[3]); 0 disables")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     return ap.parse_args()
 
@@ -110,6 +115,38 @@ def kernel_profile(wl, ffi, reps):
                          "avg_us": 1e3 * ms.value / cnt.value}
     ffi.check(lib.td_profile_enable(0))
     return out
+
+
+def sharded_extra(n, world, rank, torch, dist, ffi, reps=3):
+    """BASELINE configs[3]: ONE n x n perf.jl instance row-sharded over all ranks, one RCCL MAX
+    all-reduce of the packed bid keys per bidding round (taxidispatcher_amd/sharded.py).  Reported
+    next to the headline value, never inside it."""
+    from taxidispatcher_amd import sharded
+    row0, nrows, _ = sharded.shard_bounds(n, world, rank)
+    rows = torch.empty((max(nrows, 1), n), dtype=torch.int32, device="cuda")
+    times, total = [], None
+    for it in range(reps + 1):
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        if nrows:
+            ffi.check(ffi.lib().td_gen_uniform(n, 7, 10, 40, row0, nrows, rows.data_ptr()))
+        sh = sharded.HipShard(n, row0, nrows, rows)
+        try:
+            _, total = sharded.solve_sharded(sh, dist)
+        finally:
+            sh.close()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        if it > 0:
+            times.append(float(dt.item()))
+    best = min(times)
+    return {"workload": "g1 N=%d, ONE instance row-sharded over %d GPUs, RCCL MAX all-reduce of %d KiB keys per "
+                        "bidding round, finisher on rank 0 over hipIpc-mapped shards" % (n, world, n * 8 // 1024),
+            "n": n, "ms": 1e3 * best, "ms_all": [1e3 * t for t in times], "assignments_per_s": n / best,
+            "total_cost": int(total), "optimal": bool(total == 10 * n), "scaling": "strong"}
 
 
 def cpu_baseline(kind, n_gpu, seconds):
@@ -183,8 +220,15 @@ def main():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world > 1 or args.force_sharded:
+        import datetime
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local),
+                                timeout=datetime.timedelta(seconds=240))
     import taxidispatcher_amd as td
     from taxidispatcher_amd import _ffi as ffi
     td.init(local)
@@ -214,11 +258,18 @@ def main():
     stats = td.last_stats()
 
     prof = kernel_profile(wl, ffi, reps=3) if rank == 0 else {}
-    if world > 1:
+    shard_res = None
+    if world > 1 or args.force_sharded:
         dist.barrier()
+        if args.sharded_n > 0:
+            del wl.cost
+            torch.cuda.empty_cache()
+            try:
+                shard_res = sharded_extra(args.sharded_n, world, rank, torch, dist, ffi)
+            except Exception as e:  # keep the headline line even if the extra leg fails
+                shard_res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
     n = args.n
     ms_per_step = 1e3 * dt / args.steps
@@ -250,11 +301,19 @@ def main():
         "whole_step_algorithmic_GBps": 8.0 * n * n * world * args.steps / dt / 1e9,
         "total_cost": int(total), "solver_stats": stats, "kernels": prof, "roofline": roof,
     }
+    if shard_res is not None:
+        line["sharded_single_instance"] = shard_res
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.workload, n, args.cpu_seconds)
-    print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+    # RCCL prints a version banner through C stdio: drain it so the JSON line is the LAST line
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -112,6 +112,42 @@ TD_API int td_count_sum(int n, const int32_t *cost, const int32_t *row_to_col, i
 TD_API int td_gen_uniform(int n, uint64_t seed, int32_t lo, int32_t hi, int row0, int nrows,
                    int32_t *cost /* nrows*n */);
 
+/* ---- multi-GPU: row-sharded solve ---------------------------------------
+ * One process per GPU.  Rank r owns cost rows [row0, row0+nrows) x all n columns; prices and
+ * column owners are replicated.  The exchange step between ranks (one MAX all-reduce of the
+ * packed 64-bit bid keys per bidding round) is done by the CALLER with torch.distributed /
+ * RCCL on the key buffer — the library never links a collective.  Host driver:
+ * taxidispatcher_amd/sharded.py.
+ *   td_shard_compress   narrow working copy of the local rows (1, 2 or 4 bytes per cell); every
+ *                       rank must end up with the same width (caller reduces `fits` with MIN)
+ *   td_shard_bid        one Jacobi bidding round over the local free rows; writes keys[j] =
+ *                       (price << 20 | global_row + 1) with atomicMax, 0 = no bid
+ *   td_shard_apply      applies the globally reduced keys (identical on every rank) and zeroes them
+ *   td_shard_finish     augmenting-path finisher on the calling rank; shard_ptrs[k] is the base of
+ *                       shard k's compressed rows as visible from this device (own memory, peer
+ *                       memory mapped with td_ipc_open over xGMI, or a gathered copy)
+ *   td_shard_owner      get (set=0) / set (set=1) the replicated owner[] (n ints)
+ *   td_shard_total      this shard's part of the total (and of the dual bound); caller sums
+ */
+typedef struct td_shard td_shard;
+TD_API int td_shard_create(int n, int row0, int nrows, const int32_t *cost_rows, td_shard **out);
+TD_API int td_shard_destroy(td_shard *s);
+TD_API int td_shard_compress(td_shard *s, int bytes_per_cell, int *fits);
+TD_API int td_shard_begin(td_shard *s);
+TD_API int td_shard_keys_len(td_shard *s);
+TD_API int td_shard_bid(td_shard *s, int round, uint64_t *keys);
+TD_API int td_shard_apply(td_shard *s, int round, uint64_t *keys);
+TD_API int td_shard_cc(td_shard *s, void **ptr, uint64_t *bytes);
+TD_API int td_shard_finish(td_shard *s, int world, const void *const *shard_ptrs, int rows_per_shard);
+TD_API int td_shard_owner(td_shard *s, int32_t *owner, int set);
+TD_API int td_shard_price(td_shard *s, int64_t *price /* n, device */, int set);
+TD_API int td_shard_total(td_shard *s, int64_t *partial_total, int64_t *partial_dual);
+TD_API int td_shard_row_to_col(td_shard *s, int32_t *r2c_local);
+TD_API int td_ipc_export(const void *dev_ptr, void *handle64);
+TD_API int td_ipc_open(const void *handle64, void **dev_ptr);
+TD_API int td_ipc_close(void *dev_ptr);
+TD_API int td_memcpy(void *dst, const void *src, uint64_t bytes);
+
 /* ---- profiling hooks used by bench.py ---------------------------------------------- */
 #define TD_K_COST_BUILD 0
 #define TD_K_GEN 1

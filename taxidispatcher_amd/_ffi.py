@@ -38,6 +38,23 @@ SIGNATURES = {
                                     ctypes.POINTER(ctypes.c_int32)]),
     "td_gen_uniform": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int,
                                       ctypes.c_int, c_i32p]),
+    "td_shard_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p)]),
+    "td_shard_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "td_shard_compress": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    "td_shard_begin": (ctypes.c_int, [ctypes.c_void_p]),
+    "td_shard_keys_len": (ctypes.c_int, [ctypes.c_void_p]),
+    "td_shard_bid": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "td_shard_apply": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "td_shard_cc": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]),
+    "td_shard_finish": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
+    "td_shard_owner": (ctypes.c_int, [ctypes.c_void_p, c_i32p, ctypes.c_int]),
+    "td_shard_price": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "td_shard_total": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "td_shard_row_to_col": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
+    "td_ipc_export": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "td_ipc_open": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "td_ipc_close": (ctypes.c_int, [ctypes.c_void_p]),
+    "td_memcpy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
     "td_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "td_profile_get": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(ctypes.c_int64)]),

@@ -138,7 +138,7 @@ __device__ __forceinline__ T shfl_xor_t(T v, int m)
 // k_compress: one workgroup per row (grid-strided)
 // =====================================================================================
 template <typename CT, bool VEC>
-__global__ __launch_bounds__(256) void k_compress(int n, int nchunks, const int32_t *__restrict__ cost,
+__global__ __launch_bounds__(256) void k_compress(int n, int nrows, int nchunks, const int32_t *__restrict__ cost,
                                                   CT *__restrict__ cc, int32_t *__restrict__ rowmin,
                                                   int *__restrict__ ctl)
 {
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_compress(int n, int nchunks, const int3
     __shared__ int s_mn[4], s_mx[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const size_t pitch = (size_t)nchunks * E;
-    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int32_t *src = cost + (int64_t)row * n;
         int mn = INT_MAX, mx = INT_MIN;
         if (VEC) {
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_compress(int n, int nchunks, const int3
 // are issued back to back, so a 256-thread workgroup keeps 64 KiB in flight), reduced, and
 // written back narrow.  Needs n % 4 == 0, a 16-byte aligned matrix and n/4 <= THREADS*VPT.
 template <typename CT, int VPT, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nchunks, const int32_t *__restrict__ cost,
+__global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nrows, int nchunks, const int32_t *__restrict__ cost,
                                                           CT *__restrict__ cc, int32_t *__restrict__ rowmin,
                                                           int *__restrict__ ctl)
 {
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nchunks, co
     const size_t pitch = (size_t)nchunks * E;
     const int nq = n >> 2;
     int par = 0;
-    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int4 *s4 = reinterpret_cast<const int4 *>(cost + (int64_t)row * n);
         int4 v[VPT];
 #pragma unroll
@@ -298,8 +298,8 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nchunks, co
 // state init
 // =====================================================================================
 template <typename PT>
-__global__ void k_init_state(int n, int npad, PT *pk, PT padkey, int *owner, int *r2c, unsigned long long *bid,
-                             int *ctl)
+__global__ void k_init_state(int n, int npad, int nrows, PT *pk, PT padkey, int *owner, int *r2c,
+                             unsigned long long *bid, int *ctl)
 {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < npad) {
@@ -307,7 +307,7 @@ __global__ void k_init_state(int n, int npad, PT *pk, PT padkey, int *owner, int
         bid[j] = 0ull;
         owner[j] = (j < n) ? -1 : -2;
     }
-    if (j < n) r2c[j] = -1;
+    if (j < nrows) r2c[j] = -1;
     if (j < CTL_WORDS && j != CTL_FLAG) ctl[j] = 0;
 }
 
@@ -315,7 +315,8 @@ __global__ void k_init_state(int n, int npad, PT *pk, PT padkey, int *owner, int
 // k_bid: one wavefront per unassigned row
 // =====================================================================================
 template <typename CT, bool LDSP>
-__global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nchunks, const CT *__restrict__ cc,
+__global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nrows, int row0, int nchunks,
+                                                          const CT *__restrict__ cc,
                                                           const typename Tr<CT>::PT *__restrict__ pk,
                                                           const int *__restrict__ r2c,
                                                           unsigned long long *__restrict__ bid,
@@ -336,9 +337,10 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nchunks, c
         __syncthreads();
         P = sp;
     }
-    for (int row = blockIdx.x * nw + w; row < n; row += gridDim.x * nw) {
-        if (r2c[row] >= 0) continue;
-        const CT *rp = cc + (size_t)row * pitch;
+    for (int lrow = blockIdx.x * nw + w; lrow < nrows; lrow += gridDim.x * nw) {
+        if (r2c[lrow] >= 0) continue;
+        const int row = row0 + lrow;  // global row id (shards own rows [row0, row0+nrows))
+        const CT *rp = cc + (size_t)lrow * pitch;
         // Start chunk of the rotated scan.  It spreads the tie-breaks of different rows over the
         // columns (with first-index tie-breaking every row of a perf.jl instance would bid for the
         // same few columns) and changes every round, so an evicted row does not walk back to the
@@ -431,9 +433,9 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nchunks, c
 // k_assign: one thread per column
 // =====================================================================================
 template <typename PT>
-__global__ __launch_bounds__(256) void k_assign(int n, unsigned long long *__restrict__ bid, PT *__restrict__ pk,
-                                                int *__restrict__ owner, int *__restrict__ r2c, int *__restrict__ ctl,
-                                                int round)
+__global__ __launch_bounds__(256) void k_assign(int n, int nrows, int row0, unsigned long long *__restrict__ bid,
+                                                PT *__restrict__ pk, int *__restrict__ owner, int *__restrict__ r2c,
+                                                int *__restrict__ ctl, int round)
 {
     if (round > 0 && ctl[CTL_PROG + round - 1] == 0) return;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -444,9 +446,10 @@ __global__ __launch_bounds__(256) void k_assign(int n, unsigned long long *__res
             const int row = (int)(k & ((1ull << ROW_BITS) - 1)) - 1;
             const PT newp = (PT)(k >> ROW_BITS);
             const int old = owner[j];
-            if (old >= 0) r2c[old] = -1;
+            // r2c holds this shard's rows only; owner/price are replicated on every shard
+            if (old >= row0 && old < row0 + nrows) r2c[old - row0] = -1;
             owner[j] = row;
-            r2c[row] = j;
+            if (row >= row0 && row < row0 + nrows) r2c[row - row0] = j;
             pk[j] = (PT)(newp << 1) | (PT)1;
             bid[j] = 0ull;
             cnt = 1;
@@ -511,8 +514,23 @@ __device__ __forceinline__ void wave_argmin(PT &key, int &j, int &o, PT &p)
     }
 }
 
+// Row shards of the compressed matrix as seen from the finisher's device: local memory, or
+// peer memory of other GPUs mapped over xGMI (hipIpc) — row o lives in shard o / rps.
+struct ShardTab {
+    const void *p[16];
+    int rps;
+    int count;
+};
+
+template <typename CT>
+__device__ __forceinline__ const CT *shard_row(const ShardTab &tab, int o, size_t pitch)
+{
+    const int sh = (tab.count == 1) ? 0 : o / tab.rps;
+    return reinterpret_cast<const CT *>(tab.p[sh]) + (size_t)(o - sh * tab.rps) * pitch;
+}
+
 template <typename CT, int CH, bool LDSST>
-__global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const CT *__restrict__ cc,
+__global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab tab,
                                               typename Tr<CT>::PT *__restrict__ pk, int *__restrict__ owner_g,
                                               int *__restrict__ r2c, int *__restrict__ pred_g, int *__restrict__ list,
                                               int *__restrict__ ctl)
@@ -596,11 +614,12 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const CT *__re
         // reaches the frontier distance instead of scanning the whole tie class.
         unsigned long long ownedmask = padmask;
         // distances from the free row f (the row dual of f is a constant shift: left out)
+        const CT *frow = shard_row<CT>(tab, f, pitch);
 #pragma unroll
         for (int q = 0; q < CH; q++) {
             const int ch = q * T + tid;
             if (ch < nchunks) {
-                const uint4 cv = *reinterpret_cast<const uint4 *>(cc + (size_t)f * pitch + (size_t)ch * E);
+                const uint4 cv = *reinterpret_cast<const uint4 *>(frow + (size_t)ch * E);
                 uint32_t c[E];
                 unpack<CT>(cv, c);
 #pragma unroll
@@ -684,7 +703,7 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const CT *__re
                 if ((chq % T) == tid) scanned |= 1ull << ((chq / T) * E + (bj - chq * E));
             }
             // stream the row of the column's owner and relax
-            const CT *rp = cc + (size_t)o * pitch;
+            const CT *rp = shard_row<CT>(tab, o, pitch);
             const PT wstar = (PT)rp[bj] + (PREG ? bp : P[bj]);  // (o, bj) is tight: o's row dual
 #pragma unroll
             for (int q = 0; q < CH; q++) {
@@ -753,15 +772,15 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const CT *__re
 // =====================================================================================
 // k_final: total from the original costs + permutation check; k_dual: LP bound
 // =====================================================================================
-__global__ __launch_bounds__(256) void k_final(int n, const int32_t *__restrict__ cost, const int *__restrict__ r2c,
-                                               const int *__restrict__ owner, unsigned long long *__restrict__ out,
-                                               int *__restrict__ ctl)
+__global__ __launch_bounds__(256) void k_final(int n, int nrows, int row0, const int32_t *__restrict__ cost,
+                                               const int *__restrict__ r2c, const int *__restrict__ owner,
+                                               unsigned long long *__restrict__ out, int *__restrict__ ctl)
 {
     long long s = 0;
     int bad = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += gridDim.x * blockDim.x) {
         const int j = r2c[i];
-        if (j < 0 || j >= n || owner[j] != i)
+        if (j < 0 || j >= n || owner[j] != row0 + i)
             bad = 1;
         else
             s += cost[(int64_t)i * n + j];
@@ -777,9 +796,38 @@ __global__ __launch_bounds__(256) void k_final(int n, const int32_t *__restrict_
     }
 }
 
-// dual bound D = sum_i (rowmin_i + min_j (c'_ij + p_j)) - sum_j p_j ; one wave per row
+// local row_to_col from the replicated owner[] (after the finisher ran on another shard)
+__global__ void k_r2c_from_owner(int n, int nrows, int row0, const int *__restrict__ owner, int *__restrict__ r2c)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) {
+        const int o = owner[j];
+        if (o >= row0 && o < row0 + nrows) r2c[o - row0] = j;
+    }
+}
+
+// replicated prices <-> plain int64 (for the broadcast after the finisher changed them on one rank)
+template <typename PT>
+__global__ void k_price_io(int n, PT *pk, long long *plain, int set)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) {
+        if (set)
+            pk[j] = (PT)((PT)plain[j] << 1) | (PT)1;
+        else
+            plain[j] = (long long)(pk[j] >> 1);
+    }
+}
+
+__global__ void k_fill_i32(int *p, int count, int v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = v;
+}
+
+// dual bound D = sum_i (rowmin_i + min_j (c'_ij + p_j)) - sum_j p_j ; one wave per (local) row
 template <typename CT>
-__global__ __launch_bounds__(256) void k_dual(int n, int nchunks, const CT *__restrict__ cc,
+__global__ __launch_bounds__(256) void k_dual(int n, int nrows, int row0, int nchunks, const CT *__restrict__ cc,
                                               const typename Tr<CT>::PT *__restrict__ pk,
                                               const int32_t *__restrict__ rowmin, unsigned long long *__restrict__ out)
 {
@@ -788,7 +836,7 @@ __global__ __launch_bounds__(256) void k_dual(int n, int nchunks, const CT *__re
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const size_t pitch = (size_t)nchunks * E;
     long long acc = 0;
-    for (int row = blockIdx.x * nw + w; row < n; row += gridDim.x * nw) {
+    for (int row = blockIdx.x * nw + w; row < nrows; row += gridDim.x * nw) {
         const CT *rp = cc + (size_t)row * pitch;
         PT m = Tr<CT>::KMAX;
         for (int ch = lane; ch < nchunks; ch += 64) {
@@ -808,8 +856,8 @@ __global__ __launch_bounds__(256) void k_dual(int n, int nchunks, const CT *__re
         }
         if (lane == 0) acc += (long long)m + (long long)rowmin[row];
     }
-    // minus sum of prices: block 0 only
-    if (blockIdx.x == 0) {
+    // minus the sum of prices: once (block 0 of the shard that owns row 0)
+    if (blockIdx.x == 0 && row0 == 0) {
         long long ps = 0;
         for (int j = threadIdx.x; j < n; j += blockDim.x) ps += (long long)(pk[j] >> 1);
 #pragma unroll
@@ -820,29 +868,77 @@ __global__ __launch_bounds__(256) void k_dual(int n, int nchunks, const CT *__re
 }
 
 // -------------------------------------------------------------------------------------
-struct Plan {
-    int n, nchunks, npad;
-    const int32_t *d_cost;
+// host side: one Solver per cost matrix (td_assign) or per row shard (td_shard_*)
+// -------------------------------------------------------------------------------------
+}  // namespace
+
+struct td_shard {
+    int n = 0, row0 = 0, nrows = 0;
+    int bpc = 0;  // bytes per stored cell: 1, 2, 4 (0 = not compressed yet)
+    int nchunks = 0, npad = 0;
+    const int32_t *d_cost = nullptr;  // nrows x n, device
+    Buf stage, cc, price, owner, r2c, r2c_full, bid, pred, list, rowmin, misc;
+    void free_all()
+    {
+        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &misc};
+        for (Buf *b : bs) {
+            if (b->p) (void)hipFree(b->p);
+            b->p = nullptr;
+            b->cap = 0;
+        }
+    }
 };
 
+namespace {
+
+using Solver = td_shard;
+Solver g_default;  // td_assign's workspace, kept across calls
+
+int sv_prepare(Solver &sv, int n, int row0, int nrows, const int32_t *cost)
+{
+    Ctx &c = ctx();
+    sv.n = n;
+    sv.row0 = row0;
+    sv.nrows = nrows;
+    sv.bpc = 0;
+    int rc;
+    const void *d;
+    if ((rc = to_device(cost, sizeof(int32_t) * (size_t)nrows * n, sv.stage, &d))) return rc;
+    sv.d_cost = (const int32_t *)d;
+    const size_t np = (size_t)((n + 3) / 4) * 4 + 16;
+    if ((rc = ensure(sv.misc, 4096))) return rc;
+    if ((rc = ensure(sv.rowmin, sizeof(int32_t) * (size_t)std::max(nrows, 1)))) return rc;
+    if ((rc = ensure(sv.price, sizeof(int64_t) * np))) return rc;
+    if ((rc = ensure(sv.owner, sizeof(int) * np))) return rc;
+    if ((rc = ensure(sv.r2c, sizeof(int) * np))) return rc;
+    if ((rc = ensure(sv.pred, sizeof(int) * np))) return rc;
+    if ((rc = ensure(sv.list, sizeof(int) * np))) return rc;
+    if ((rc = ensure(sv.bid, sizeof(unsigned long long) * np))) return rc;
+    (void)c;
+    return TD_OK;
+}
+
 template <typename CT>
-int run_compress(const Plan &pl, bool *fits)
+int sv_compress_t(Solver &sv, bool *fits)
 {
     Ctx &c = ctx();
     constexpr int E = Tr<CT>::E;
-    const int nchunks = (pl.n + E - 1) / E;
+    const int n = sv.n, nrows = sv.nrows;
+    const int nchunks = (n + E - 1) / E;
     int rc;
-    if ((rc = ensure(c.cc, (size_t)pl.n * nchunks * 16))) return rc;
-    int *ctl = (int *)c.misc.p;
+    if ((rc = ensure(sv.cc, std::max<size_t>((size_t)nrows * nchunks * 16, 256)))) return rc;
+    int *ctl = (int *)sv.misc.p;
     TD_HIP(hipMemsetAsync(ctl, 0, sizeof(int), c.stream));
-    const bool vec = (pl.n % 4 == 0) && (((uintptr_t)pl.d_cost & 15) == 0);
-    const int grid = std::min(pl.n, c.n_cu * 8);
-    {
+    const bool vec = (n % 4 == 0) && (((uintptr_t)sv.d_cost & 15) == 0);
+    const int grid = std::max(1, std::min(nrows, c.n_cu * 8));
+    if (nrows > 0) {
         ProfScope ps(TD_K_COMPRESS);
-        const int nq = pl.n / 4;
+        const int nq = n / 4;
+        CT *cc = (CT *)sv.cc.p;
+        int32_t *rm = (int32_t *)sv.rowmin.p;
         if (vec && nq <= 256 * 16) {
-            const int g2 = std::min(pl.n, c.n_cu * 4);
-#define TD_CR(VPT) k_compress_reg<CT, VPT, 256><<<g2, 256, 0, c.stream>>>(pl.n, nchunks, pl.d_cost, (CT *)c.cc.p, (int32_t *)c.rowmin.p, ctl)
+            const int g2 = std::max(1, std::min(nrows, c.n_cu * 4));
+#define TD_CR(VPT) k_compress_reg<CT, VPT, 256><<<g2, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl)
             if (nq <= 256) TD_CR(1);
             else if (nq <= 512) TD_CR(2);
             else if (nq <= 1024) TD_CR(4);
@@ -850,136 +946,186 @@ int run_compress(const Plan &pl, bool *fits)
             else TD_CR(16);
 #undef TD_CR
         } else if (vec && nq <= 1024 * 16) {
-            k_compress_reg<CT, 16, 1024><<<std::min(pl.n, c.n_cu * 2), 1024, 0, c.stream>>>(pl.n, nchunks, pl.d_cost, (CT *)c.cc.p,
-                                                                                            (int32_t *)c.rowmin.p, ctl);
+            k_compress_reg<CT, 16, 1024><<<std::max(1, std::min(nrows, c.n_cu * 2)), 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl);
         } else if (vec)
-            k_compress<CT, true><<<grid, 256, 0, c.stream>>>(pl.n, nchunks, pl.d_cost, (CT *)c.cc.p, (int32_t *)c.rowmin.p, ctl);
+            k_compress<CT, true><<<grid, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl);
         else
-            k_compress<CT, false><<<grid, 256, 0, c.stream>>>(pl.n, nchunks, pl.d_cost, (CT *)c.cc.p, (int32_t *)c.rowmin.p, ctl);
+            k_compress<CT, false><<<grid, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl);
     }
     TD_HIP(hipGetLastError());
     TD_HIP(hipMemcpyAsync(c.pinned, ctl, sizeof(int), hipMemcpyDeviceToHost, c.stream));
     TD_HIP(hipStreamSynchronize(c.stream));
     *fits = (((int *)c.pinned)[0] == 0);
+    if (*fits) {
+        sv.bpc = (int)sizeof(CT);
+        sv.nchunks = nchunks;
+        sv.npad = nchunks * E;
+    }
+    return TD_OK;
+}
+
+int sv_compress(Solver &sv, int bpc, bool *fits)
+{
+    switch (bpc) {
+        case 1: return sv_compress_t<uint8_t>(sv, fits);
+        case 2: return sv_compress_t<uint16_t>(sv, fits);
+        case 4: return sv_compress_t<uint32_t>(sv, fits);
+    }
+    return fail(TD_EINVAL, "bytes per cell must be 1, 2 or 4");
+}
+
+template <typename CT>
+int sv_begin_t(Solver &sv)
+{
+    Ctx &c = ctx();
+    using PT = typename Tr<CT>::PT;
+    const PT padkey = (PT)(Tr<CT>::BIG << 1) | (PT)1;
+    k_init_state<PT><<<(std::max(sv.npad, (int)CTL_WORDS) + 255) / 256, 256, 0, c.stream>>>(
+        sv.n, sv.npad, sv.nrows, (PT *)sv.price.p, padkey, (int *)sv.owner.p, (int *)sv.r2c.p,
+        (unsigned long long *)sv.bid.p, (int *)sv.misc.p);
+    TD_HIP(hipMemsetAsync((char *)sv.misc.p + 1024, 0, 16, c.stream));
+    TD_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+template <typename CT>
+int sv_bid_t(Solver &sv, int r, unsigned long long *keys)
+{
+    Ctx &c = ctx();
+    using PT = typename Tr<CT>::PT;
+    const int n = sv.n, nrows = sv.nrows;
+    if (nrows == 0) return TD_OK;
+    const size_t lds_prices = (size_t)sv.npad * sizeof(PT);
+    const bool can_lds = lds_prices <= 128 * 1024 && n >= 2048 && nrows >= 1024;
+    const int tie_evict = (r >= 1) ? g_tie_evict : 0;
+    ProfScope ps(TD_K_BID);
+    if (can_lds && r < g_lds_rounds) {
+        if (lds_prices > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_bid<CT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prices);
+        const int grid = std::min((nrows + 15) / 16, c.n_cu);
+        k_bid<CT, true><<<grid, 1024, lds_prices, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
+                                                              (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict);
+    } else {
+        k_bid<CT, false><<<(nrows + 3) / 4, 256, 0, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
+                                                                (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict);
+    }
+    TD_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+template <typename CT>
+int sv_apply_t(Solver &sv, int r, unsigned long long *keys)
+{
+    Ctx &c = ctx();
+    using PT = typename Tr<CT>::PT;
+    ProfScope ps(TD_K_ASSIGN);
+    k_assign<PT><<<(sv.n + 255) / 256, 256, 0, c.stream>>>(sv.n, sv.nrows, sv.row0, keys, (PT *)sv.price.p, (int *)sv.owner.p,
+                                                           (int *)sv.r2c.p, (int *)sv.misc.p, r);
+    TD_HIP(hipGetLastError());
     return TD_OK;
 }
 
 template <typename CT, int CH, bool LDSST>
-void launch_sap(int n, int nchunks, int T, size_t shm)
+void launch_sap(Solver &sv, const ShardTab &tab, int *r2c_full, int T, size_t shm)
 {
     Ctx &c = ctx();
     using PT = typename Tr<CT>::PT;
     if (shm > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)k_sap<CT, CH, LDSST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    k_sap<CT, CH, LDSST><<<1, T, shm, c.stream>>>(n, nchunks, (const CT *)c.cc.p, (PT *)c.price.p, (int *)c.owner.p,
-                                                  (int *)c.r2c.p, (int *)c.pred.p, (int *)c.list.p, (int *)c.misc.p);
+    k_sap<CT, CH, LDSST><<<1, T, shm, c.stream>>>(sv.n, sv.nchunks, tab, (PT *)sv.price.p, (int *)sv.owner.p, r2c_full,
+                                                  (int *)sv.pred.p, (int *)sv.list.p, (int *)sv.misc.p);
+}
+
+// finisher; r2c_full is indexed by GLOBAL row (== sv.r2c for an unsharded solve)
+template <typename CT>
+int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
+{
+    constexpr int E = Tr<CT>::E;
+    const int n = sv.n, nchunks = sv.nchunks, npad = sv.npad;
+    int CH = 1;
+    while (CH * 1024 < nchunks) CH *= 2;
+    int T = (nchunks + CH - 1) / CH;
+    T = std::min(1024, std::max(64, ((T + 63) / 64) * 64));
+    const size_t st = (size_t)npad * 2 * sizeof(int);  // owner[] + pred[]
+    const bool lds = st <= 150 * 1024;
+    const size_t shm = lds ? st : 0;
+    if (CH * E > 64) return fail(TD_ERANGE, "n=%d too large for the single-workgroup finisher", n);
+    ProfScope ps(TD_K_SAP);
+#define TD_SAP(CHV)                                                    \
+    if (lds) launch_sap<CT, CHV, true>(sv, tab, r2c_full, T, shm);     \
+    else launch_sap<CT, CHV, false>(sv, tab, r2c_full, T, shm)
+    switch (CH) {
+        case 1: TD_SAP(1); break;
+        case 2: TD_SAP(2); break;
+        case 4: TD_SAP(4); break;
+        case 8:
+            if constexpr (E <= 8) { TD_SAP(8); }
+            break;
+        case 16:
+            if constexpr (E <= 4) { TD_SAP(16); }
+            break;
+        default: return fail(TD_ERANGE, "n=%d too large for the single-workgroup finisher", n);
+    }
+#undef TD_SAP
+    TD_HIP(hipGetLastError());
+    return TD_OK;
 }
 
 template <typename CT>
-int run_solve(const Plan &pl, int64_t *total, int64_t *dual)
+int sv_totals_t(Solver &sv, bool want_dual)
 {
     Ctx &c = ctx();
     using PT = typename Tr<CT>::PT;
-    constexpr int E = Tr<CT>::E;
-    const int n = pl.n;
-    const int nchunks = (n + E - 1) / E;
-    const int npad = nchunks * E;
-    int *ctl = (int *)c.misc.p;
-    unsigned long long *out = (unsigned long long *)((char *)c.misc.p + 1024);
-    PT *pk = (PT *)c.price.p;
-    const PT padkey = (PT)(Tr<CT>::BIG << 1) | (PT)1;
-
-    k_init_state<PT><<<(std::max(npad, (int)CTL_WORDS) + 255) / 256, 256, 0, c.stream>>>(
-        n, npad, pk, padkey, (int *)c.owner.p, (int *)c.r2c.p, (unsigned long long *)c.bid.p, ctl);
-    TD_HIP(hipMemsetAsync(out, 0, 16, c.stream));
-
-    // ---- Jacobi bidding rounds -------------------------------------------------------
-    const int max_rounds = g_max_rounds;
-    const size_t lds_prices = (size_t)npad * sizeof(PT);
-    const bool can_lds = lds_prices <= 128 * 1024 && n >= 2048;
-    if (can_lds && lds_prices > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)k_bid<CT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prices);
-    for (int r = 0; r < max_rounds; r++) {
-        const int tie_evict = (r >= 1) ? g_tie_evict : 0;
-        {
-            ProfScope ps(TD_K_BID);
-            if (can_lds && r < g_lds_rounds) {
-                const int grid = std::min((n + 15) / 16, c.n_cu);
-                k_bid<CT, true><<<grid, 1024, lds_prices, c.stream>>>(n, nchunks, (const CT *)c.cc.p, pk, (const int *)c.r2c.p,
-                                                                      (unsigned long long *)c.bid.p, ctl, r, tie_evict);
-            } else {
-                k_bid<CT, false><<<(n + 3) / 4, 256, 0, c.stream>>>(n, nchunks, (const CT *)c.cc.p, pk, (const int *)c.r2c.p,
-                                                                    (unsigned long long *)c.bid.p, ctl, r, tie_evict);
-            }
-        }
-        {
-            ProfScope ps(TD_K_ASSIGN);
-            k_assign<PT><<<(n + 255) / 256, 256, 0, c.stream>>>(n, (unsigned long long *)c.bid.p, pk, (int *)c.owner.p,
-                                                                (int *)c.r2c.p, ctl, r);
-        }
-    }
+    unsigned long long *out = (unsigned long long *)((char *)sv.misc.p + 1024);
+    ProfScope ps(TD_K_FINAL);
+    if (sv.nrows > 0)
+        k_final<<<std::min((sv.nrows + 255) / 256, 256), 256, 0, c.stream>>>(sv.n, sv.nrows, sv.row0, sv.d_cost, (const int *)sv.r2c.p,
+                                                                            (const int *)sv.owner.p, out, (int *)sv.misc.p);
+    if (want_dual && (sv.nrows > 0 || sv.row0 == 0))
+        k_dual<CT><<<std::max(1, std::min((sv.nrows + 3) / 4, c.n_cu * 8)), 256, 0, c.stream>>>(
+            sv.n, sv.nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p, (const int32_t *)sv.rowmin.p, out);
     TD_HIP(hipGetLastError());
+    return TD_OK;
+}
 
-    // ---- shortest augmenting path finisher ------------------------------------------
-    {
-        int CH = 1;
-        while (CH * 1024 < nchunks) CH *= 2;
-        int T = (nchunks + CH - 1) / CH;
-        T = std::min(1024, std::max(64, ((T + 63) / 64) * 64));
-        const size_t st = (size_t)npad * 2 * sizeof(int);  // owner[] + pred[]
-        const bool lds = st <= 150 * 1024;
-        const size_t shm = lds ? st : 0;
-        if (CH * E > 64) return fail(TD_ERANGE, "n=%d too large for the single-workgroup finisher", n);
-        ProfScope ps(TD_K_SAP);
-#define TD_SAP(CHV)                                              \
-    if (lds) launch_sap<CT, CHV, true>(n, nchunks, T, shm);      \
-    else launch_sap<CT, CHV, false>(n, nchunks, T, shm)
-        switch (CH) {
-            case 1: TD_SAP(1); break;
-            case 2: TD_SAP(2); break;
-            case 4: TD_SAP(4); break;
-            case 8:
-                if constexpr (E <= 8) { TD_SAP(8); }
-                break;
-            case 16:
-                if constexpr (E <= 4) { TD_SAP(16); }
-                break;
-            default: return fail(TD_ERANGE, "n=%d too large for the single-workgroup finisher", n);
-        }
-#undef TD_SAP
-    }
-    TD_HIP(hipGetLastError());
+#define TD_DISPATCH(sv, CALL, ...)                                  \
+    do {                                                            \
+        switch ((sv).bpc) {                                         \
+            case 1: rc = CALL<uint8_t>(__VA_ARGS__); break;         \
+            case 2: rc = CALL<uint16_t>(__VA_ARGS__); break;        \
+            case 4: rc = CALL<uint32_t>(__VA_ARGS__); break;        \
+            default: rc = fail(TD_EINVAL, "shard is not compressed yet"); \
+        }                                                           \
+    } while (0)
 
-    // ---- total, check, certificate ---------------------------------------------------
-    {
-        ProfScope ps(TD_K_FINAL);
-        k_final<<<std::min((n + 255) / 256, 256), 256, 0, c.stream>>>(n, pl.d_cost, (const int *)c.r2c.p, (const int *)c.owner.p, out, ctl);
-        if (dual) {
-            k_dual<CT><<<std::min((n + 3) / 4, c.n_cu * 8), 256, 0, c.stream>>>(n, nchunks, (const CT *)c.cc.p, pk, (const int32_t *)c.rowmin.p, out);
-        }
-    }
-    TD_HIP(hipGetLastError());
+// read back ctl + totals (one sync)
+int sv_readback(Solver &sv, int64_t *total, int64_t *dual, int max_rounds)
+{
+    Ctx &c = ctx();
     char *pin = (char *)c.pinned;
-    TD_HIP(hipMemcpyAsync(pin, ctl, CTL_WORDS * sizeof(int), hipMemcpyDeviceToHost, c.stream));
-    TD_HIP(hipMemcpyAsync(pin + 1024, out, 16, hipMemcpyDeviceToHost, c.stream));
+    TD_HIP(hipMemcpyAsync(pin, sv.misc.p, CTL_WORDS * sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    TD_HIP(hipMemcpyAsync(pin + 1024, (char *)sv.misc.p + 1024, 16, hipMemcpyDeviceToHost, c.stream));
     TD_HIP(hipStreamSynchronize(c.stream));
     const int *hctl = (const int *)pin;
     if (hctl[CTL_ERR]) return fail(TD_EINTERNAL, "device-side consistency check failed (code %d)", hctl[CTL_ERR]);
-    *total = ((const int64_t *)(pin + 1024))[0];
+    if (total) *total = ((const int64_t *)(pin + 1024))[0];
     if (dual) *dual = ((const int64_t *)(pin + 1024))[1];
     int rounds = 0;
-    for (int r = 0; r < max_rounds; r++)
+    for (int r = 0; r < max_rounds && r < 48; r++)
         if (hctl[CTL_PROG + r] > 0) rounds++;
     c.stats[0] = rounds;
     c.stats[1] = 0;
     c.stats[2] = hctl[CTL_NFREE];
     c.stats[3] = hctl[CTL_STEPS];
-    c.stats[4] = sizeof(CT);
+    c.stats[4] = sv.bpc;
     return TD_OK;
 }
 
 }  // namespace
 
+// =====================================================================================
+// td_assign
+// =====================================================================================
 extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_t *total, int64_t *dual_bound)
 {
     TD_REQUIRE_INIT();
@@ -993,23 +1139,12 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     }
     if (!cost || !row_to_col) return fail(TD_EINVAL, "null array");
     if (n >= (1 << ROW_BITS) - 1) return fail(TD_ERANGE, "n=%d exceeds the packed bid key", n);
+    Solver &sv = g_default;
     int rc;
-    const void *d_cost_v;
-    if ((rc = to_device(cost, sizeof(int32_t) * (size_t)n * n, c.stage_d, &d_cost_v))) return rc;
-    Plan pl{n, 0, 0, (const int32_t *)d_cost_v};
-    const int npad_max = ((n + 3) / 4) * 4 + 16;
-    if ((rc = ensure(c.misc, 4096))) return rc;
-    if ((rc = ensure(c.rowmin, sizeof(int32_t) * (size_t)n))) return rc;
-    if ((rc = ensure(c.price, sizeof(int64_t) * (size_t)npad_max))) return rc;
-    if ((rc = ensure(c.owner, sizeof(int) * (size_t)npad_max))) return rc;
-    if ((rc = ensure(c.r2c, sizeof(int) * (size_t)npad_max))) return rc;
-    if ((rc = ensure(c.pred, sizeof(int) * (size_t)npad_max))) return rc;
-    if ((rc = ensure(c.list, sizeof(int) * (size_t)npad_max))) return rc;
-    if ((rc = ensure(c.bid, sizeof(unsigned long long) * (size_t)npad_max))) return rc;
-
+    if ((rc = sv_prepare(sv, n, 0, n, cost))) return rc;
     int64_t tot = 0, dual = 0;
     if (n == 1) {
-        TD_HIP(hipMemcpyAsync(c.pinned, pl.d_cost, sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipMemcpyAsync(c.pinned, sv.d_cost, sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
         TD_HIP(hipStreamSynchronize(c.stream));
         tot = dual = ((int32_t *)c.pinned)[0];
         int32_t zero = 0;
@@ -1023,27 +1158,256 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         return TD_OK;
     }
     bool fits = false;
-    if ((rc = run_compress<uint8_t>(pl, &fits))) return rc;
-    if (fits) {
-        rc = run_solve<uint8_t>(pl, &tot, dual_bound ? &dual : nullptr);
-    } else {
-        if ((rc = run_compress<uint16_t>(pl, &fits))) return rc;
-        if (fits) {
-            rc = run_solve<uint16_t>(pl, &tot, dual_bound ? &dual : nullptr);
-        } else {
-            if ((rc = run_compress<uint32_t>(pl, &fits))) return rc;
-            if (!fits) return fail(TD_ERANGE, "row cost range exceeds 2^32-2");
-            rc = run_solve<uint32_t>(pl, &tot, dual_bound ? &dual : nullptr);
-        }
+    for (int bpc : {1, 2, 4}) {
+        if ((rc = sv_compress(sv, bpc, &fits))) return rc;
+        if (fits) break;
     }
+    if (!fits) return fail(TD_ERANGE, "row cost range exceeds 2^32-2");
+    TD_DISPATCH(sv, sv_begin_t, sv);
     if (rc) return rc;
+    const int max_rounds = g_max_rounds;
+    for (int r = 0; r < max_rounds; r++) {
+        TD_DISPATCH(sv, sv_bid_t, sv, r, (unsigned long long *)sv.bid.p);
+        if (rc) return rc;
+        TD_DISPATCH(sv, sv_apply_t, sv, r, (unsigned long long *)sv.bid.p);
+        if (rc) return rc;
+    }
+    ShardTab tab{};
+    tab.p[0] = sv.cc.p;
+    tab.rps = n;
+    tab.count = 1;
+    TD_DISPATCH(sv, sv_finish_t, sv, tab, (int *)sv.r2c.p);
+    if (rc) return rc;
+    TD_DISPATCH(sv, sv_totals_t, sv, dual_bound != nullptr);
+    if (rc) return rc;
+    if ((rc = sv_readback(sv, &tot, &dual, max_rounds))) return rc;
     if (is_device_ptr(row_to_col)) {
-        TD_HIP(hipMemcpyAsync(row_to_col, c.r2c.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c.stream));
+        TD_HIP(hipMemcpyAsync(row_to_col, sv.r2c.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c.stream));
     } else {
-        TD_HIP(hipMemcpyAsync(row_to_col, c.r2c.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipMemcpyAsync(row_to_col, sv.r2c.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c.stream));
     }
     TD_HIP(hipStreamSynchronize(c.stream));
     if (total) *total = tot;
     if (dual_bound) *dual_bound = dual;
     return TD_OK;
 }
+
+extern "C" void td_assign_release_workspace(void) { g_default.free_all(); }
+
+// =====================================================================================
+// row-sharded solve: device-side pieces; the collective is the caller's
+// =====================================================================================
+extern "C" {
+
+int td_shard_create(int n, int row0, int nrows, const int32_t *cost_rows, td_shard **out)
+{
+    TD_REQUIRE_INIT();
+    read_tunables();
+    if (!out) return fail(TD_EINVAL, "null out");
+    if (n < 2 || row0 < 0 || nrows < 0 || row0 + nrows > n) return fail(TD_EINVAL, "bad shard geometry n=%d row0=%d nrows=%d", n, row0, nrows);
+    if (n >= (1 << ROW_BITS) - 1) return fail(TD_ERANGE, "n=%d exceeds the packed bid key", n);
+    if (nrows > 0 && !cost_rows) return fail(TD_EINVAL, "null cost rows");
+    td_shard *s = new td_shard();
+    int rc = sv_prepare(*s, n, row0, nrows, nrows ? cost_rows : (const int32_t *)ctx().pinned);
+    if (rc) {
+        s->free_all();
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return TD_OK;
+}
+
+int td_shard_destroy(td_shard *s)
+{
+    TD_REQUIRE_INIT();
+    if (!s) return TD_OK;
+    (void)hipStreamSynchronize(ctx().stream);
+    s->free_all();
+    delete s;
+    return TD_OK;
+}
+
+int td_shard_compress(td_shard *s, int bytes_per_cell, int *fits)
+{
+    TD_REQUIRE_INIT();
+    if (!s || !fits) return fail(TD_EINVAL, "null argument");
+    bool f = false;
+    int rc = sv_compress(*s, bytes_per_cell, &f);
+    *fits = f ? 1 : 0;
+    return rc;
+}
+
+int td_shard_begin(td_shard *s)
+{
+    TD_REQUIRE_INIT();
+    if (!s) return fail(TD_EINVAL, "null shard");
+    int rc;
+    TD_DISPATCH(*s, sv_begin_t, *s);
+    return rc;
+}
+
+int td_shard_keys_len(td_shard *s) { return s ? s->npad : 0; }
+
+int td_shard_bid(td_shard *s, int round, uint64_t *keys)
+{
+    TD_REQUIRE_INIT();
+    if (!s || !keys) return fail(TD_EINVAL, "null argument");
+    if (!is_device_ptr(keys)) return fail(TD_EINVAL, "bid keys must be device memory");
+    int rc;
+    TD_DISPATCH(*s, sv_bid_t, *s, round, (unsigned long long *)keys);
+    return rc;
+}
+
+int td_shard_apply(td_shard *s, int round, uint64_t *keys)
+{
+    TD_REQUIRE_INIT();
+    if (!s || !keys) return fail(TD_EINVAL, "null argument");
+    int rc;
+    TD_DISPATCH(*s, sv_apply_t, *s, round, (unsigned long long *)keys);
+    return rc;
+}
+
+int td_shard_cc(td_shard *s, void **ptr, uint64_t *bytes)
+{
+    TD_REQUIRE_INIT();
+    if (!s || !s->bpc) return fail(TD_EINVAL, "shard not compressed");
+    if (ptr) *ptr = s->cc.p;
+    if (bytes) *bytes = (uint64_t)s->nrows * s->nchunks * 16;
+    return TD_OK;
+}
+
+// Runs the finisher on THIS rank; shard_ptrs[k] = device-visible base of shard k's compressed
+// rows (own memory, hipIpc-mapped peer memory, or a gathered copy).
+int td_shard_finish(td_shard *s, int world, const void *const *shard_ptrs, int rows_per_shard)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (!s || !shard_ptrs || world < 1 || world > 16) return fail(TD_EINVAL, "bad finisher arguments (world <= 16)");
+    ShardTab tab{};
+    for (int k = 0; k < world; k++) tab.p[k] = shard_ptrs[k];
+    tab.rps = rows_per_shard;
+    tab.count = world;
+    int rc;
+    const int n = s->n;
+    if ((rc = ensure(s->r2c_full, sizeof(int) * (size_t)(n + 16)))) return rc;
+    int *full = (int *)s->r2c_full.p;
+    k_fill_i32<<<(n + 255) / 256, 256, 0, c.stream>>>(full, n, -1);
+    k_r2c_from_owner<<<(n + 255) / 256, 256, 0, c.stream>>>(n, n, 0, (const int *)s->owner.p, full);
+    TD_DISPATCH(*s, sv_finish_t, *s, tab, full);
+    if (rc) return rc;
+    // the finisher moved assignments: rebuild this rank's local row_to_col from owner[]
+    if (s->nrows > 0) {
+        k_fill_i32<<<(s->nrows + 255) / 256, 256, 0, c.stream>>>((int *)s->r2c.p, s->nrows, -1);
+        k_r2c_from_owner<<<(n + 255) / 256, 256, 0, c.stream>>>(n, s->nrows, s->row0, (const int *)s->owner.p, (int *)s->r2c.p);
+    }
+    TD_HIP(hipGetLastError());
+    TD_HIP(hipStreamSynchronize(c.stream));
+    return TD_OK;
+}
+
+// owner[] (n ints, global row per column): get it after the finisher / set it on the other ranks
+int td_shard_owner(td_shard *s, int32_t *owner, int set)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (!s || !owner) return fail(TD_EINVAL, "null argument");
+    const size_t bytes = sizeof(int32_t) * (size_t)s->n;
+    if (set) {
+        TD_HIP(hipMemcpyAsync(s->owner.p, owner, bytes, is_device_ptr(owner) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c.stream));
+        if (s->nrows > 0) {
+            k_fill_i32<<<(s->nrows + 255) / 256, 256, 0, c.stream>>>((int *)s->r2c.p, s->nrows, -1);
+            k_r2c_from_owner<<<(s->n + 255) / 256, 256, 0, c.stream>>>(s->n, s->nrows, s->row0, (const int *)s->owner.p, (int *)s->r2c.p);
+        }
+        TD_HIP(hipGetLastError());
+    } else {
+        TD_HIP(hipMemcpyAsync(owner, s->owner.p, bytes, is_device_ptr(owner) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c.stream));
+    }
+    TD_HIP(hipStreamSynchronize(c.stream));
+    return TD_OK;
+}
+
+// partial total (and dual bound) over this shard's rows; the caller sums over ranks
+int td_shard_total(td_shard *s, int64_t *partial_total, int64_t *partial_dual)
+{
+    TD_REQUIRE_INIT();
+    if (!s) return fail(TD_EINVAL, "null shard");
+    int rc;
+    TD_HIP(hipMemsetAsync((char *)s->misc.p + 1024, 0, 16, ctx().stream));
+    TD_DISPATCH(*s, sv_totals_t, *s, partial_dual != nullptr);
+    if (rc) return rc;
+    return sv_readback(*s, partial_total, partial_dual, g_max_rounds);
+}
+
+// final column prices (n x int64): get them on the finisher's rank / set them on the others so
+// that every rank evaluates its part of the dual bound with the same prices
+int td_shard_price(td_shard *s, int64_t *price, int set)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (!s || !price || !s->bpc) return fail(TD_EINVAL, "bad argument");
+    if (!is_device_ptr(price)) return fail(TD_EINVAL, "price buffer must be device memory");
+    const int g = (s->n + 255) / 256;
+    if (s->bpc == 1)
+        k_price_io<int32_t><<<g, 256, 0, c.stream>>>(s->n, (int32_t *)s->price.p, (long long *)price, set);
+    else
+        k_price_io<int64_t><<<g, 256, 0, c.stream>>>(s->n, (int64_t *)s->price.p, (long long *)price, set);
+    TD_HIP(hipGetLastError());
+    TD_HIP(hipStreamSynchronize(c.stream));
+    return TD_OK;
+}
+
+int td_shard_row_to_col(td_shard *s, int32_t *r2c_local)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (!s || (!r2c_local && s->nrows)) return fail(TD_EINVAL, "null argument");
+    if (s->nrows == 0) return TD_OK;
+    TD_HIP(hipMemcpyAsync(r2c_local, s->r2c.p, sizeof(int32_t) * (size_t)s->nrows,
+                          is_device_ptr(r2c_local) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c.stream));
+    TD_HIP(hipStreamSynchronize(c.stream));
+    return TD_OK;
+}
+
+// ---- peer mapping of shards over xGMI (one process per GPU => hipIpc) -----------------
+int td_ipc_export(const void *dev_ptr, void *handle64)
+{
+    TD_REQUIRE_INIT();
+    static_assert(sizeof(hipIpcMemHandle_t) <= 64, "handle size");
+    if (!dev_ptr || !handle64) return fail(TD_EINVAL, "null argument");
+    hipIpcMemHandle_t h;
+    TD_HIP(hipIpcGetMemHandle(&h, const_cast<void *>(dev_ptr)));
+    memset(handle64, 0, 64);
+    memcpy(handle64, &h, sizeof(h));
+    return TD_OK;
+}
+
+int td_ipc_open(const void *handle64, void **dev_ptr)
+{
+    TD_REQUIRE_INIT();
+    if (!handle64 || !dev_ptr) return fail(TD_EINVAL, "null argument");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    TD_HIP(hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return TD_OK;
+}
+
+int td_ipc_close(void *dev_ptr)
+{
+    TD_REQUIRE_INIT();
+    if (!dev_ptr) return TD_OK;
+    TD_HIP(hipIpcCloseMemHandle(dev_ptr));
+    return TD_OK;
+}
+
+int td_memcpy(void *dst, const void *src, uint64_t bytes)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (!dst || !src) return fail(TD_EINVAL, "null argument");
+    TD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c.stream));
+    TD_HIP(hipStreamSynchronize(c.stream));
+    return TD_OK;
+}
+
+}  // extern "C"

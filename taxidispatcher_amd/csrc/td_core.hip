@@ -271,6 +271,8 @@ __global__ void k_count_sum(int n, const int32_t *cost, const int32_t *row_to_co
 // =====================================================================================
 // API
 // =====================================================================================
+extern "C" void td_assign_release_workspace(void);
+
 extern "C" {
 
 int td_version(void) { return 100; }
@@ -309,6 +311,7 @@ void td_shutdown(void)
     if (!c.inited) return;
     (void)hipSetDevice(c.device);
     (void)hipDeviceSynchronize();
+    td_assign_release_workspace();
     Buf *bufs[] = {&c.stage_a, &c.stage_b, &c.stage_c, &c.stage_d, &c.stage_out, &c.cc, &c.price, &c.owner, &c.r2c,
                    &c.bid,     &c.pred,    &c.rowmin,  &c.misc,    &c.list,      &c.lcm_a, &c.lcm_b, &c.lcm_c, &c.lcm_d};
     for (Buf *b : bufs) {

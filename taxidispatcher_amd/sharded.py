@@ -1,0 +1,285 @@
+"""Row-sharded optimal assignment across GPUs.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).  Rank r owns cost
+rows [r*rps, (r+1)*rps) x all n columns (rps = ceil(n / world)); prices and column owners are
+replicated.  Per bidding round there is exactly ONE exchange step: a MAX all-reduce of the n
+packed 64-bit bid keys (512 KiB at n = 65 536) — every rank then applies the identical update, so
+no second exchange and no termination message is needed (rounds are a fixed count; a converged
+round makes all later device kernels exit immediately).  The few rows left free are finished by
+the augmenting-path workgroup on rank 0, which reads the other ranks' compressed shards in place
+through hipIpc peer mappings over xGMI (fallback: gather copies).  owner[] is then broadcast and
+each rank sums its rows' costs; one SUM all-reduce of a scalar gives the total.
+
+The reference has no multi-process path for the solve (its only parallel construct is the
+8-process pool finder, findpool.c:138-164); this design is new, not a translation.
+
+`solve_sharded` is written against a small shard interface so that the collective logic is
+testable on CPU with gloo (tests/test_sharded_gloo.py supplies a numpy model of a shard); the
+product shard is `HipShard`, which needs the HIP library and a GPU.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _ffi
+
+DEFAULT_ROUNDS = 16
+
+
+def shard_bounds(n, world, rank):
+    """rows owned by `rank`: (row0, nrows, rows_per_shard) with a uniform shard height."""
+    rps = (n + world - 1) // world
+    row0 = min(n, rank * rps)
+    return row0, max(0, min(rps, n - row0)), rps
+
+
+class HipShard:
+    """One rank's rows on its GPU, through the C ABI (td_shard_*)."""
+
+    def __init__(self, n, row0, nrows, cost_rows):
+        import torch
+        self.torch = torch
+        self.lib = _ffi.lib()
+        self.n, self.row0, self.nrows = n, row0, nrows
+        self._cost = cost_rows  # keep alive: the library reads it again for the total
+        h = ctypes.c_void_p()
+        _ffi.check(self.lib.td_shard_create(n, row0, nrows, _ffi.addr(cost_rows) if nrows else None,
+                                            ctypes.byref(h)))
+        self.h = h
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self._opened = []
+
+    def close(self):
+        for p in self._opened:
+            self.lib.td_ipc_close(ctypes.c_void_p(p))
+        self._opened = []
+        if self.h:
+            self.lib.td_shard_destroy(self.h)
+            self.h = None
+
+    # -- compression width agreement
+    def compress(self, bytes_per_cell):
+        fits = ctypes.c_int(0)
+        _ffi.check(self.lib.td_shard_compress(self.h, bytes_per_cell, ctypes.byref(fits)))
+        return bool(fits.value)
+
+    def begin(self):
+        _ffi.check(self.lib.td_shard_begin(self.h))
+
+    def new_keys(self):
+        return self.torch.zeros(self.lib.td_shard_keys_len(self.h) + 16, dtype=self.torch.int64, device=self.device)
+
+    def bid(self, rnd, keys):
+        _ffi.check(self.lib.td_shard_bid(self.h, rnd, keys.data_ptr()))
+        _ffi.check(self.lib.td_synchronize())  # the collective runs on torch's stream
+
+    def apply(self, rnd, keys):
+        _ffi.check(self.lib.td_shard_apply(self.h, rnd, keys.data_ptr()))
+        _ffi.check(self.lib.td_synchronize())
+
+    # -- finisher support
+    def export_handle(self):
+        """64-byte hipIpc handle of the compressed shard (uint8 tensor on the device)."""
+        ptr = ctypes.c_void_p()
+        nbytes = ctypes.c_uint64()
+        _ffi.check(self.lib.td_shard_cc(self.h, ctypes.byref(ptr), ctypes.byref(nbytes)))
+        buf = (ctypes.c_ubyte * 64)()
+        rc = self.lib.td_ipc_export(ptr, buf)
+        ok = rc == 0
+        return self.torch.tensor(list(buf) + [1 if ok else 0], dtype=self.torch.uint8, device=self.device)
+
+    def cc_ref(self):
+        ptr = ctypes.c_void_p()
+        _ffi.check(self.lib.td_shard_cc(self.h, ctypes.byref(ptr), None))
+        return int(ptr.value or 0)
+
+    def empty_owner(self):
+        return self.torch.empty(self.n, dtype=self.torch.int32, device=self.device)
+
+    def open_handle(self, handle_u8):
+        raw = bytes(handle_u8[:64].cpu().numpy().tobytes())
+        buf = (ctypes.c_ubyte * 64).from_buffer_copy(raw)
+        out = ctypes.c_void_p()
+        rc = self.lib.td_ipc_open(buf, ctypes.byref(out))
+        if rc != 0:
+            return None
+        self._opened.append(out.value)
+        return out.value
+
+    def cc_copy(self):
+        """a torch uint8 copy of the compressed shard (gather fallback)"""
+        ptr = ctypes.c_void_p()
+        nbytes = ctypes.c_uint64()
+        _ffi.check(self.lib.td_shard_cc(self.h, ctypes.byref(ptr), ctypes.byref(nbytes)))
+        t = self.torch.empty(max(1, nbytes.value), dtype=self.torch.uint8, device=self.device)
+        if nbytes.value:
+            _ffi.check(self.lib.td_memcpy(t.data_ptr(), ptr, nbytes.value))
+        return t
+
+    def finish(self, refs, rps):
+        """refs[k]: device address (own / hipIpc-mapped) or a torch uint8 device tensor (gathered copy)"""
+        ptrs = [r.data_ptr() if hasattr(r, "data_ptr") else int(r) for r in refs]
+        arr = (ctypes.c_void_p * len(ptrs))(*[ctypes.c_void_p(p) for p in ptrs])
+        _ffi.check(self.lib.td_shard_finish(self.h, len(ptrs), arr, rps))
+
+    def get_owner(self):
+        t = self.torch.empty(self.n, dtype=self.torch.int32, device=self.device)
+        _ffi.check(self.lib.td_shard_owner(self.h, t.data_ptr(), 0))
+        return t
+
+    def set_owner(self, owner):
+        _ffi.check(self.lib.td_shard_owner(self.h, owner.data_ptr(), 1))
+
+    def get_price(self):
+        t = self.torch.empty(self.n, dtype=self.torch.int64, device=self.device)
+        _ffi.check(self.lib.td_shard_price(self.h, t.data_ptr(), 0))
+        return t
+
+    def empty_price(self):
+        return self.torch.empty(self.n, dtype=self.torch.int64, device=self.device)
+
+    def set_price(self, price):
+        _ffi.check(self.lib.td_shard_price(self.h, price.data_ptr(), 1))
+
+    def totals(self, want_dual):
+        tot = ctypes.c_int64(0)
+        dual = ctypes.c_int64(0)
+        _ffi.check(self.lib.td_shard_total(self.h, ctypes.byref(tot), ctypes.byref(dual) if want_dual else None))
+        return int(tot.value), int(dual.value)
+
+    def row_to_col(self):
+        r = np.empty(self.nrows, np.int32)
+        _ffi.check(self.lib.td_shard_row_to_col(self.h, r.ctypes.data if self.nrows else None))
+        return r
+
+    def scalar_tensor(self, values, dtype=None):
+        return self.torch.tensor(values, dtype=dtype or self.torch.int64, device=self.device)
+
+
+def _staged(dist, t):
+    """gloo has no device collectives on every build: stage device tensors through the host."""
+    return dist.get_backend() == "gloo" and getattr(t, "is_cuda", False)
+
+
+def all_reduce(dist, t, op):
+    if _staged(dist, t):
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op)
+
+
+def broadcast(dist, t, src):
+    if _staged(dist, t):
+        c = t.cpu()
+        dist.broadcast(c, src)
+        t.copy_(c)
+    else:
+        dist.broadcast(t, src)
+
+
+def all_gather_equal(dist, t):
+    """all_gather of equally sized tensors -> list"""
+    world = dist.get_world_size()
+    if _staged(dist, t):
+        c = t.cpu()
+        out = [c.new_empty(c.shape) for _ in range(world)]
+        dist.all_gather(out, c)
+        return [o.to(t.device) for o in out]
+    out = [t.new_empty(t.shape) for _ in range(world)]
+    dist.all_gather(out, t)
+    return out
+
+
+def solve_sharded(shard, dist, rounds=DEFAULT_ROUNDS, want_dual=False, use_ipc=None):
+    """Collective part of the sharded solve; `shard` implements the HipShard interface and `dist`
+    is torch.distributed (initialised). Returns (local row_to_col, total[, dual])."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = shard.n
+    _, _, rps = shard_bounds(n, world, rank)
+    MIN, MAX, SUM = dist.ReduceOp.MIN, dist.ReduceOp.MAX, dist.ReduceOp.SUM
+    # 1. agree on the storage width (every rank must use the same one)
+    for width in (1, 2, 4):
+        flag = shard.scalar_tensor([1 if shard.compress(width) else 0])
+        if world > 1:
+            all_reduce(dist, flag, MIN)
+        if int(flag[0].item()) == 1:
+            break
+    else:
+        raise _ffi.TdError("row cost range exceeds 2^32-2 on some rank")
+    shard.begin()
+    # 2. Jacobi bidding rounds: ONE exchange step per round
+    keys = shard.new_keys()
+    for r in range(rounds):
+        shard.bid(r, keys)
+        if world > 1:
+            all_reduce(dist, keys, MAX)
+        shard.apply(r, keys)
+    # 3. finisher on rank 0 over peer-mapped (or gathered) shards
+    if use_ipc is None:
+        use_ipc = os.environ.get("TD_SHARD_GATHER", "0") != "1"
+    refs = None
+    if world == 1:
+        refs = [shard.cc_ref()]
+    else:
+        ipc_ok = shard.scalar_tensor([0])
+        if use_ipc and hasattr(shard, "export_handle"):
+            hs = all_gather_equal(dist, shard.export_handle())
+            if rank == 0:
+                good = all(int(x[64].item()) == 1 for x in hs)
+                refs = [shard.cc_ref()]
+                for k in range(1, world):
+                    p = shard.open_handle(hs[k]) if good else None
+                    if p is None:
+                        good = False
+                        break
+                    refs.append(p)
+                ipc_ok = shard.scalar_tensor([1 if good else 0])
+            broadcast(dist, ipc_ok, 0)
+        if int(ipc_ok[0].item()) != 1:
+            # fallback: every shard's compressed rows are copied to rank 0 (padded to one size)
+            mine = shard.cc_copy()
+            sz = shard.scalar_tensor([int(mine.numel())])
+            all_reduce(dist, sz, MAX)
+            padded = mine.new_zeros(int(sz[0].item()))
+            padded[:mine.numel()] = mine
+            refs = all_gather_equal(dist, padded)
+    if rank == 0:
+        shard.finish(refs, rps)
+        owner = shard.get_owner()
+    else:
+        owner = shard.empty_owner()
+    if world > 1:
+        broadcast(dist, owner, 0)
+        if rank != 0:
+            shard.set_owner(owner)
+        if want_dual:  # the finisher moved prices on rank 0: the certificate needs them everywhere
+            price = shard.get_price() if rank == 0 else shard.empty_price()
+            broadcast(dist, price, 0)
+            if rank != 0:
+                shard.set_price(price)
+    del refs
+    # 4. totals: each rank sums its own rows
+    tot, dual = shard.totals(want_dual)
+    t = shard.scalar_tensor([tot, dual])
+    if world > 1:
+        all_reduce(dist, t, SUM)
+    r2c = shard.row_to_col()
+    if want_dual:
+        return r2c, int(t[0].item()), int(t[1].item())
+    return r2c, int(t[0].item())
+
+
+def assign_sharded(cost_rows, n, want_dual=False, rounds=DEFAULT_ROUNDS, dist=None):
+    """Convenience entry: this rank's rows (torch CUDA int32 [nrows, n] or numpy) -> result."""
+    if dist is None:
+        import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    row0, nrows, _ = shard_bounds(n, world, rank)
+    sh = HipShard(n, row0, nrows, cost_rows)
+    try:
+        return solve_sharded(sh, dist, rounds, want_dual)
+    finally:
+        sh.close()

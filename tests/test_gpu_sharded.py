@@ -1,0 +1,110 @@
+"""GPU test of the row-sharded path with the REAL device shards (HipShard through the C ABI):
+two processes share GPU 0, host collectives over gloo (RCCL needs one GPU per rank; the driver
+exercises that at round end with bench.py --gpus N).  Covers the hipIpc peer mapping between
+processes and the gather fallback."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _collect(q, procs, count, limit=240):
+    """results from the workers; fails fast when a worker died instead of waiting for the queue"""
+    import queue
+    import time
+    outs, t0 = [], time.time()
+    while len(outs) < count:
+        try:
+            outs.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > limit:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise AssertionError("sharded worker failed: exit codes %s" % [p.exitcode for p in procs])
+    return sorted(outs)
+
+
+def _worker(rank, world, port, n, seed, use_ipc, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import taxidispatcher_amd as td
+    from taxidispatcher_amd import sharded
+    from oracle import oracle
+    td.init(0)
+    row0, nrows, rps = sharded.shard_bounds(n, world, rank)
+    rows = torch.from_numpy(oracle.gen_uniform(n, seed, 10, 40, row0, nrows)).cuda()
+    sh = sharded.HipShard(n, row0, nrows, rows)
+    try:
+        r2c, total, dual = sharded.solve_sharded(sh, dist, want_dual=True, use_ipc=use_ipc)
+    finally:
+        sh.close()
+    q.put((rank, r2c.tolist(), total, dual))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,use_ipc", [(512, True), (2050, True), (1000, False)])
+def test_two_ranks_one_gpu(n, use_ipc):
+    from oracle import oracle
+    seed = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, seed, use_ipc, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = _collect(q, procs, 2)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    cost = oracle.gen_uniform(n, seed, 10, 40)
+    ref = oracle.assign(cost)[0]
+    r2c = np.array(outs[0][1] + outs[1][1])
+    assert outs[0][2] == outs[1][2] == ref
+    assert outs[0][3] == outs[1][3] == ref      # duality certificate summed over shards
+    assert sorted(r2c.tolist()) == list(range(n))
+    assert int(cost[np.arange(n), r2c].sum()) == ref
+
+
+def test_single_rank_shard_api_matches_td_assign(td):
+    """world = 1 through the shard API == td_assign (same kernels, same keys)."""
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle
+    from taxidispatcher_amd import sharded
+    if not dist.is_initialized():
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(_free_port())
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    n = 777
+    cost = oracle.gen_uniform(n, 11, 10, 40)
+    sh = sharded.HipShard(n, 0, n, torch.from_numpy(cost).cuda())
+    try:
+        r2c, total, dual = sharded.solve_sharded(sh, dist, want_dual=True)
+    finally:
+        sh.close()
+    r_ref, t_ref = td.assign(cost)
+    assert total == t_ref == dual == oracle.assign(cost)[0]
+    assert np.array_equal(r2c, r_ref)
+    dist.destroy_process_group()
