@@ -83,7 +83,7 @@ enum {
 constexpr int ROW_BITS = 20;
 
 // tunables (env TD_MAX_ROUNDS / TD_TIE_EVICT / TD_LDS_ROUNDS, read once at td_assign)
-int g_max_rounds = 16, g_tie_evict = 1, g_lds_rounds = 1;
+int g_max_rounds = 16, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1;
 void read_tunables()
 {
     static bool done = false;
@@ -92,6 +92,7 @@ void read_tunables()
     if (const char *e = getenv("TD_MAX_ROUNDS")) g_max_rounds = std::max(1, std::min(48, atoi(e)));
     if (const char *e = getenv("TD_TIE_EVICT")) g_tie_evict = atoi(e) != 0;
     if (const char *e = getenv("TD_LDS_ROUNDS")) g_lds_rounds = std::max(0, atoi(e));
+    if (const char *e = getenv("TD_SAP8")) g_sap8 = atoi(e) != 0;
 }
 
 // ---- unpack one 16-byte chunk into E cost values -----------------------------------
@@ -770,6 +771,217 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab
 }
 
 // =====================================================================================
+// k_sap8: the finisher specialised for u8 rows / int32 prices with ONE 16-column chunk per
+// thread (n <= 16 384).  Same algorithm as k_sap; the step loop is cut to ~1/3 of the VALU
+// instructions (it is issue-bound: 16 waves share 4 SIMDs):
+//   * per column one packed argmin key am = dist<<5 | owned<<4 | slot, so the local argmin is 8
+//     v_min3_u32 and the winner's slot falls out of the key;
+//   * a scanned column gets am = MAX, dist = 0 and its pending dual change folded into the
+//     cached price at scan time, so relax needs no "scanned" test (Dijkstra never improves a
+//     finalised column) and the dual update is price + mind;
+//   * pred[] lives in registers and is flushed to LDS once per search (4 ds_write_b128).
+// =====================================================================================
+template <bool LDSST>
+__global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTab tab, int32_t *__restrict__ pk,
+                                               int *__restrict__ owner_g, int *__restrict__ r2c,
+                                               int *__restrict__ pred_g, int *__restrict__ list,
+                                               int *__restrict__ ctl)
+{
+    constexpr int E = 16;
+    constexpr uint32_t AMAX = 0x7FFFFFFFu;
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ uint32_t s_rk[2][16];
+    __shared__ int s_rp[2][16];
+    __shared__ int s_rj[2][16];
+    __shared__ int s_wcnt[16];
+    __shared__ int s_nfree;
+
+    const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
+    const int npad = nchunks * E;
+    const size_t pitch = (size_t)npad;
+    int32_t *P = pk;
+    int *OWN = LDSST ? reinterpret_cast<int *>(smem) : owner_g;
+    int *PRED = LDSST ? reinterpret_cast<int *>(smem + (size_t)npad * sizeof(int)) : pred_g;
+
+    for (int j = tid; j < npad; j += T) {
+        P[j] = pk[j] >> 1;
+        if (LDSST) OWN[j] = owner_g[j];
+    }
+    if (tid == 0) s_nfree = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < n; r0 += T) {
+        const int r = r0 + tid;
+        const bool fr = r < n && r2c[r] < 0;
+        const unsigned long long m = __ballot(fr);
+        if (lane == 0) s_wcnt[w] = __popcll(m);
+        __syncthreads();
+        int base = s_nfree;
+        for (int k = 0; k < w; k++) base += s_wcnt[k];
+        if (fr) list[base + __popcll(m & ((1ull << lane) - 1ull))] = r;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int k = 0; k < nw; k++) tot += s_wcnt[k];
+            s_nfree += tot;
+        }
+        __syncthreads();
+    }
+    const int nfree = s_nfree;
+    __syncthreads();
+
+    const bool has = tid < nchunks;
+    const int jbase = tid * E;
+    long long steps = 0;
+    int par = 0;
+    bool bad = false;
+    for (int fi = 0; fi < nfree && !bad; fi++) {
+        const int f = list[fi];
+        // key[e] = (dist+1) << 5 | owned << 4 | e ; a finalised or non-existent column keeps only
+        // its low 5 bits: it can never be improved (any candidate key is >= it) and, seen through
+        // "key - 32" (unsigned wrap), never wins the argmin.
+        uint32_t key[E];
+        int32_t preg[E], predr[E];
+        uint32_t sc = 0;
+        {
+            uint32_t c[E];
+            if (has) {
+                const uint4 cv = *reinterpret_cast<const uint4 *>(shard_row<uint8_t>(tab, f, pitch) + (size_t)jbase);
+                unpack<uint8_t>(cv, c);
+            }
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int j = jbase + e;
+                const bool valid = has && j < n;
+                const int32_t p = valid ? P[j] : 0;
+                const int o = valid ? OWN[j] : -2;
+                preg[e] = p;
+                predr[e] = f;
+                const uint32_t low = ((o != -1) ? 16u : 0u) | (uint32_t)e;
+                key[e] = valid ? (((c[e] + (uint32_t)p + 1u) << 5) | low) : low;
+            }
+        }
+        int32_t mind = 0;
+        int endcol = -1;
+        for (int guard = 0; guard <= npad; guard++) {
+            uint32_t m0 = min(min(key[0] - 32u, key[1] - 32u), min(key[2] - 32u, key[3] - 32u));
+            uint32_t m1 = min(min(key[4] - 32u, key[5] - 32u), min(key[6] - 32u, key[7] - 32u));
+            uint32_t m2 = min(min(key[8] - 32u, key[9] - 32u), min(key[10] - 32u, key[11] - 32u));
+            uint32_t m3 = min(min(key[12] - 32u, key[13] - 32u), min(key[14] - 32u, key[15] - 32u));
+            const uint32_t m = min(min(m0, m1), min(m2, m3));
+            // wave stage
+            uint32_t mw = wave_umin32(m);
+            int L = __ffsll((long long)__ballot(m == mw)) - 1;
+            int pw = 0;
+            switch (mw & 15u) {
+#define TD_SEL(k)                                            \
+    case k:                                                  \
+        pw = __builtin_amdgcn_readlane(preg[k], L);          \
+        break;
+                TD_SEL(0) TD_SEL(1) TD_SEL(2) TD_SEL(3) TD_SEL(4) TD_SEL(5) TD_SEL(6) TD_SEL(7)
+                TD_SEL(8) TD_SEL(9) TD_SEL(10) TD_SEL(11) TD_SEL(12) TD_SEL(13) TD_SEL(14) TD_SEL(15)
+#undef TD_SEL
+            }
+            int jw = ((w << 6) + L) * E + (int)(mw & 15u);
+            if (nw > 1) {
+                if (lane == 0) {
+                    s_rk[par][w] = mw;
+                    s_rj[par][w] = jw;
+                    s_rp[par][w] = pw;
+                }
+                __syncthreads();
+                const bool hv = lane < nw;
+                const uint32_t k2 = hv ? s_rk[par][lane] : 0xFFFFFFFFu;
+                const int j2 = hv ? s_rj[par][lane] : 0;
+                const int p2 = hv ? s_rp[par][lane] : 0;
+                mw = wave_umin32(k2);
+                L = __ffsll((long long)__ballot(k2 == mw)) - 1;
+                jw = __builtin_amdgcn_readlane(j2, L);
+                pw = __builtin_amdgcn_readlane(p2, L);
+                par ^= 1;
+            }
+            if (mw >= 0xF0000000u) {  // nothing left to scan: cannot happen with a free column around
+                bad = true;
+                break;
+            }
+            const int bj = jw;
+            const int32_t bd = (int32_t)(mw >> 5);
+            if (!(mw & 16u)) {  // free column reached
+                mind = bd;
+                endcol = bj;
+                break;
+            }
+            const int o = OWN[bj];
+            steps++;
+            {  // finalise column bj in its owner thread; its pending dual change goes into preg
+                const bool mine = (tid == (bj >> 4));
+                switch (bj & 15) {
+#define TD_FIN(k)                                   \
+    case k:                                         \
+        preg[k] = mine ? preg[k] - bd : preg[k];    \
+        key[k] = mine ? (key[k] & 31u) : key[k];    \
+        break;
+                    TD_FIN(0) TD_FIN(1) TD_FIN(2) TD_FIN(3) TD_FIN(4) TD_FIN(5) TD_FIN(6) TD_FIN(7)
+                    TD_FIN(8) TD_FIN(9) TD_FIN(10) TD_FIN(11) TD_FIN(12) TD_FIN(13) TD_FIN(14) TD_FIN(15)
+#undef TD_FIN
+                }
+                sc |= mine ? (1u << (bj & 15)) : 0u;
+            }
+            const uint8_t *rp = shard_row<uint8_t>(tab, o, pitch);
+            const int32_t t1 = bd - ((int32_t)rp[bj] + pw) + 1;  // dist(bj) - row dual of o (+1: key bias)
+            if (has) {
+                const uint4 cv = *reinterpret_cast<const uint4 *>(rp + (size_t)jbase);
+                uint32_t c[E];
+                unpack<uint8_t>(cv, c);
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const uint32_t h1 = (uint32_t)((int32_t)c[e] + preg[e] + t1);
+                    const uint32_t hk = (h1 << 5) | (key[e] & 31u);
+                    const bool better = hk < key[e];
+                    key[e] = better ? hk : key[e];
+                    predr[e] = better ? o : predr[e];
+                }
+            }
+        }
+        if (endcol < 0) {
+            bad = true;
+            break;
+        }
+        if (has) {
+            // dual update of finalised columns (their -dist is already folded into preg) + pred flush
+#pragma unroll
+            for (int e = 0; e < E; e++)
+                if ((sc >> e) & 1u) P[jbase + e] = preg[e] + mind;
+#pragma unroll
+            for (int e = 0; e < E; e += 4)
+                *reinterpret_cast<int4 *>(&PRED[jbase + e]) = make_int4(predr[e], predr[e + 1], predr[e + 2], predr[e + 3]);
+        }
+        __syncthreads();
+        if (tid == 0) {  // flip the path
+            int j = endcol;
+            for (int hop = 0; hop <= n; hop++) {
+                const int i = PRED[j];
+                OWN[j] = i;
+                const int jn = r2c[i];
+                r2c[i] = j;
+                j = jn;
+                if (i == f) break;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int j = tid; j < npad; j += T) {
+        pk[j] = (int32_t)(P[j] << 1) | 1;
+        if (LDSST && j < n) owner_g[j] = OWN[j];
+    }
+    if (tid == 0) {
+        ctl[CTL_NFREE] = nfree;
+        ctl[CTL_STEPS] = (int)(steps > INT_MAX ? INT_MAX : steps);
+        if (bad) atomicOr(&ctl[CTL_ERR], 2);
+    }
+}
+
+// =====================================================================================
 // k_final: total from the original costs + permutation check; k_dual: LP bound
 // =====================================================================================
 __global__ __launch_bounds__(256) void k_final(int n, int nrows, int row0, const int32_t *__restrict__ cost,
@@ -1051,6 +1263,22 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
     const size_t shm = lds ? st : 0;
     if (CH * E > 64) return fail(TD_ERANGE, "n=%d too large for the single-workgroup finisher", n);
     ProfScope ps(TD_K_SAP);
+    if constexpr (sizeof(CT) == 1) {
+        if (CH == 1 && g_sap8) {
+            Ctx &c = ctx();
+            if (lds) {
+                if (shm > 48 * 1024)
+                    (void)hipFuncSetAttribute((const void *)k_sap8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                k_sap8<true><<<1, T, shm, c.stream>>>(sv.n, sv.nchunks, tab, (int32_t *)sv.price.p, (int *)sv.owner.p, r2c_full,
+                                                      (int *)sv.pred.p, (int *)sv.list.p, (int *)sv.misc.p);
+            } else {
+                k_sap8<false><<<1, T, 0, c.stream>>>(sv.n, sv.nchunks, tab, (int32_t *)sv.price.p, (int *)sv.owner.p, r2c_full,
+                                                     (int *)sv.pred.p, (int *)sv.list.p, (int *)sv.misc.p);
+            }
+            TD_HIP(hipGetLastError());
+            return TD_OK;
+        }
+    }
 #define TD_SAP(CHV)                                                    \
     if (lds) launch_sap<CT, CHV, true>(sv, tab, r2c_full, T, shm);     \
     else launch_sap<CT, CHV, false>(sv, tab, r2c_full, T, shm)

@@ -1,0 +1,93 @@
+"""Golden trace of the reference's committed simulation (simulations/simulog_solv.txt t=0..49,
+input simulations/taxi_demand.txt) replayed through the tick-loop harness.
+
+CPU tier: path operations by the oracle -> pins the oracle's cost build, Java-variant LCM and
+exact solver against output the REFERENCE itself committed (incl. `OPT count=32` of its first
+GLPK call).  GPU tier: the same replay with every path operation on the MI355X."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+GOLD = os.path.join(HERE, "golden")
+
+
+def golden_lines():
+    return [l.strip() for l in open(os.path.join(GOLD, "simulog_solv_t0_49.txt")).read().split("\n") if l.strip()]
+
+
+def tick49():
+    return json.load(open(os.path.join(GOLD, "tick49_instance.json")))
+
+
+def test_replay_matches_reference_log_oracle_backend():
+    from sim_backend import OracleBackend
+    from taxidispatcher_amd import simulator
+    sim = simulator.Simulator(simulator.read_demand(os.path.join(GOLD, "taxi_demand.txt.gz")), OracleBackend())
+    log = [l.strip() for l in sim.run(50)]
+    gold = golden_lines()
+    assert len(gold) == 50 and log == gold
+    assert gold[49].endswith("Sent to solver: demand=218, supply=600. ; OPT count=32")
+    assert sim.m["max_model_size"] <= 1300 and sim.m["max_solver_size"] == 600
+
+
+def test_tick49_instance_oracle():
+    from oracle import oracle
+    g = tick49()
+    n, cost = oracle.cost_build(g["cab_to"], g["dem_from"], None, g["fill"], g["threshold"])
+    assert n == 600 and len(g["cab_to"]) == 600 and len(g["dem_from"]) == 218
+    t, r, u, v = oracle.assign(cost)
+    assert t == g["total"] == 142000088 == 568 * 250000 + 88
+    assert oracle.count_sum(cost, r) == (g["real_total"], g["opt_count"]) == (88, 32)
+
+
+@pytest.mark.gpu
+def test_replay_matches_reference_log_gpu(td):
+    from taxidispatcher_amd import simulator
+    sim = simulator.Simulator(simulator.read_demand(os.path.join(GOLD, "taxi_demand.txt.gz")))  # HipBackend
+    log = [l.strip() for l in sim.run(50)]
+    assert log == golden_lines()
+
+
+@pytest.mark.gpu
+def test_tick49_instance_gpu(td):
+    from oracle import oracle
+    g = tick49()
+    n, cost = td.cost_build(g["cab_to"], g["dem_from"], None, fill=g["fill"], threshold=g["threshold"])
+    assert np.array_equal(cost, oracle.cost_build(g["cab_to"], g["dem_from"], None, g["fill"], g["threshold"])[1])
+    r2c, total, dual = td.assign(cost, want_dual=True)
+    assert total == g["total"] == dual
+    assert td.count_sum(n, cost, r2c) == g["real_total"]
+    x = td.expand_x(n, r2c)
+    opt_count = int(((x.reshape(n, n) == 1) & (cost < 250000)).sum())   # Simulator.java:378-383
+    assert opt_count == g["opt_count"] == 32
+
+
+@pytest.mark.gpu
+def test_config5_tick_pipeline_gpu(td):
+    """BASELINE config 5: a 1300-cab tick re-solved with LCM pre-reduce — cost build (n=1300) ->
+    LCM down to 600 -> shrink -> cost build -> optimal assignment, against the oracle."""
+    from oracle import oracle
+    from taxidispatcher_amd.simulator import BIG_COST, DROP_TIME, MAX_NON_LCM
+    rng = np.random.default_rng(49)
+    cab_to = rng.integers(0, 50, 1300)
+    dem_from = rng.integers(0, 50, 900)
+    n, cost = td.cost_build(cab_to, dem_from, None, fill=BIG_COST, threshold=DROP_TIME)
+    n_o, cost_o = oracle.cost_build(cab_to, dem_from, None, BIG_COST, DROP_TIME)
+    assert n == 1300 and np.array_equal(cost, cost_o)
+    pairs, lm = td.LCM_simulator(cost, max_non_lcm=MAX_NON_LCM)
+    _, rows, cols, lm_o = oracle.lcm(cost_o, mask=BIG_COST, stop_value_on=1, stop_value=BIG_COST,
+                                     stop_size=MAX_NON_LCM, sum_below=BIG_COST, java_scan=1)
+    assert pairs == list(zip(rows.tolist(), cols.tolist())) and lm == lm_o and len(pairs) == 700
+    keep_c = np.setdiff1d(np.arange(1300), rows)
+    keep_d = np.setdiff1d(np.arange(900), cols)
+    n2, cost2 = td.cost_build(cab_to[keep_c], dem_from[keep_d], None, fill=BIG_COST, threshold=DROP_TIME)
+    assert n2 == 600
+    r2c, total, dual = td.assign(cost2, want_dual=True)
+    t_o, r_o, _, _ = oracle.assign(cost2)
+    assert total == t_o == dual
+    assert td.count_sum(n2, cost2, r2c) == oracle.count_sum(cost2, r_o)[0]
