@@ -83,7 +83,7 @@ enum {
 constexpr int ROW_BITS = 20;
 
 // tunables (env TD_MAX_ROUNDS / TD_TIE_EVICT / TD_LDS_ROUNDS, read once at td_assign)
-int g_max_rounds = 16, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1;
+int g_max_rounds = 12, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1, g_row_rounds = 2, g_cgrid = 6, g_creg = 1;
 void read_tunables()
 {
     static bool done = false;
@@ -93,6 +93,9 @@ void read_tunables()
     if (const char *e = getenv("TD_TIE_EVICT")) g_tie_evict = atoi(e) != 0;
     if (const char *e = getenv("TD_LDS_ROUNDS")) g_lds_rounds = std::max(0, atoi(e));
     if (const char *e = getenv("TD_SAP8")) g_sap8 = atoi(e) != 0;
+    if (const char *e = getenv("TD_ROW_ROUNDS")) g_row_rounds = std::max(0, atoi(e));
+    if (const char *e = getenv("TD_CGRID")) g_cgrid = std::max(1, atoi(e));
+    if (const char *e = getenv("TD_CREG")) g_creg = atoi(e) != 0;
 }
 
 // ---- unpack one 16-byte chunk into E cost values -----------------------------------
@@ -422,6 +425,108 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nrows, int
             // A tie on an owned column raises no price.  With tie_evict the row still takes the
             // column (complementary slackness stays exact, the previous owner re-bids next round
             // and usually finds a free tied column); otherwise it is left to the finisher.
+            if (j1 < n && (!(owned && inc == 0) || tie_evict)) {
+                const PT newp = (P[j1] >> 1) + inc;
+                atomicMax(&bid[j1], ((unsigned long long)newp << ROW_BITS) | (unsigned long long)(row + 1));
+            }
+        }
+    }
+}
+
+// k_bid_row: the same bidding round with one WORKGROUP (256 threads) per unassigned row — every
+// lane issues all its 16-byte loads of the row at once, so a row costs one memory round trip
+// instead of four.  Used for the later rounds, where a handful of rows are left and the round is
+// pure latency.
+template <typename CT>
+__global__ __launch_bounds__(256) void k_bid_row(int n, int nrows, int row0, int nchunks, const CT *__restrict__ cc,
+                                                 const typename Tr<CT>::PT *__restrict__ P,
+                                                 const int *__restrict__ r2c, unsigned long long *__restrict__ bid,
+                                                 const int *__restrict__ ctl, int round, int tie_evict)
+{
+    using PT = typename Tr<CT>::PT;
+    constexpr int E = Tr<CT>::E;
+    constexpr int U = 4;
+    __shared__ PT s_k[4], s_x[4];
+    __shared__ int s_p[4];
+    if (round > 0 && ctl[CTL_PROG + round - 1] == 0) return;
+    const int lrow = blockIdx.x;
+    if (lrow >= nrows || r2c[lrow] >= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const size_t pitch = (size_t)nchunks * E;
+    const int row = row0 + lrow;
+    const CT *rp = cc + (size_t)lrow * pitch;
+    const uint32_t hsh = ((uint32_t)row + 1u) * 0x9E3779B1u + (uint32_t)round * 0x85EBCA6Bu;
+    const int rot = (int)(((uint64_t)(hsh ^ (hsh >> 15)) * (uint64_t)nchunks) >> 32);
+    PT k1 = Tr<CT>::KMAX, k2 = Tr<CT>::KMAX;
+    int pos1 = 0;
+    for (int t0 = tid; t0 < nchunks; t0 += 256 * U) {
+        uint4 cv[U];
+        int chs[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = t0 + 256 * u;
+            int ch = t + rot;
+            if (ch >= nchunks) ch -= nchunks;
+            chs[u] = t < nchunks ? ch : -1;
+            if (t < nchunks) cv[u] = *reinterpret_cast<const uint4 *>(rp + (size_t)ch * E);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (chs[u] < 0) continue;
+            const int t = t0 + 256 * u;
+            uint32_t c[E];
+            unpack<CT>(cv[u], c);
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const PT key = (PT)(2 * (PT)c[e]) + P[(size_t)chs[u] * E + e];
+                const bool lt = key < k1;
+                const PT mx = key > k1 ? key : k1;
+                k2 = k2 < mx ? k2 : mx;
+                pos1 = lt ? (t * E + e) : pos1;
+                k1 = lt ? key : k1;
+            }
+        }
+    }
+    PT bk = k1;
+    int bp = (k1 == Tr<CT>::KMAX) ? INT_MAX : pos1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        PT ok = shfl_xor_t(bk, o);
+        int op = __shfl_xor(bp, o);
+        if (ok < bk || (ok == bk && op < bp)) {
+            bk = ok;
+            bp = op;
+        }
+    }
+    const bool winner = (k1 == bk) && (bp == pos1) && (k1 != Tr<CT>::KMAX);
+    PT x = winner ? k2 : k1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        PT ox = shfl_xor_t(x, o);
+        x = ox < x ? ox : x;
+    }
+    if (lane == 0) {
+        s_k[w] = bk;
+        s_p[w] = bp;
+        s_x[w] = x;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int wb = 0;
+        for (int k = 1; k < 4; k++)
+            if (s_k[k] < s_k[wb] || (s_k[k] == s_k[wb] && s_p[k] < s_p[wb])) wb = k;
+        bk = s_k[wb];
+        bp = s_p[wb];
+        x = s_x[wb];
+        for (int k = 0; k < 4; k++)
+            if (k != wb && s_k[k] < x) x = s_k[k];
+        if (bp != INT_MAX) {
+            const int t1 = bp / E;
+            int ch = t1 + rot;
+            if (ch >= nchunks) ch -= nchunks;
+            const int j1 = ch * E + (bp - t1 * E);
+            const PT inc = (x == Tr<CT>::KMAX) ? (PT)0 : (PT)((x >> 1) - (bk >> 1));
+            const bool owned = (bk & 1) != 0;
             if (j1 < n && (!(owned && inc == 0) || tie_evict)) {
                 const PT newp = (P[j1] >> 1) + inc;
                 atomicMax(&bid[j1], ((unsigned long long)newp << ROW_BITS) | (unsigned long long)(row + 1));
@@ -781,6 +886,9 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab
 //     finalised column) and the dual update is price + mind;
 //   * pred[] lives in registers and is flushed to LDS once per search (4 ds_write_b128).
 // =====================================================================================
+constexpr int SAP_W = 16;  // columns of one tie class finalised per step
+constexpr int SAP_G = 4;   // rows streamed per load group
+
 template <bool LDSST>
 __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTab tab, int32_t *__restrict__ pk,
                                                int *__restrict__ owner_g, int *__restrict__ r2c,
@@ -791,6 +899,9 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
     constexpr uint32_t AMAX = 0x7FFFFFFFu;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_rk[2][16];
+    __shared__ int s_rc[2][16];
+    __shared__ int s_bj[2][SAP_W];
+    __shared__ int s_bp[2][SAP_W];
     __shared__ int s_rp[2][16];
     __shared__ int s_rj[2][16];
     __shared__ int s_wcnt[16];
@@ -868,77 +979,111 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
             uint32_t m2 = min(min(key[8] - 32u, key[9] - 32u), min(key[10] - 32u, key[11] - 32u));
             uint32_t m3 = min(min(key[12] - 32u, key[13] - 32u), min(key[14] - 32u, key[15] - 32u));
             const uint32_t m = min(min(m0, m1), min(m2, m3));
-            // wave stage
-            uint32_t mw = wave_umin32(m);
-            int L = __ffsll((long long)__ballot(m == mw)) - 1;
-            int pw = 0;
-            switch (mw & 15u) {
-#define TD_SEL(k)                                            \
-    case k:                                                  \
-        pw = __builtin_amdgcn_readlane(preg[k], L);          \
-        break;
-                TD_SEL(0) TD_SEL(1) TD_SEL(2) TD_SEL(3) TD_SEL(4) TD_SEL(5) TD_SEL(6) TD_SEL(7)
-                TD_SEL(8) TD_SEL(9) TD_SEL(10) TD_SEL(11) TD_SEL(12) TD_SEL(13) TD_SEL(14) TD_SEL(15)
-#undef TD_SEL
-            }
-            int jw = ((w << 6) + L) * E + (int)(mw & 15u);
+            // wave stage: min key, and how many lanes sit at the same DISTANCE as the wave minimum
+            const uint32_t mw = wave_umin32(m);
+            const unsigned long long tieb = __ballot((m >> 5) == (mw >> 5));
+            uint32_t mg = mw;
+            int total = __popcll(tieb), base = 0;
             if (nw > 1) {
                 if (lane == 0) {
                     s_rk[par][w] = mw;
-                    s_rj[par][w] = jw;
-                    s_rp[par][w] = pw;
+                    s_rc[par][w] = total;
                 }
                 __syncthreads();
                 const bool hv = lane < nw;
                 const uint32_t k2 = hv ? s_rk[par][lane] : 0xFFFFFFFFu;
-                const int j2 = hv ? s_rj[par][lane] : 0;
-                const int p2 = hv ? s_rp[par][lane] : 0;
-                mw = wave_umin32(k2);
-                L = __ffsll((long long)__ballot(k2 == mw)) - 1;
-                jw = __builtin_amdgcn_readlane(j2, L);
-                pw = __builtin_amdgcn_readlane(p2, L);
-                par ^= 1;
+                const int c2 = hv ? s_rc[par][lane] : 0;
+                mg = wave_umin32(k2);
+                const unsigned long long wb = __ballot(hv && (k2 >> 5) == (mg >> 5));  // waves at the global distance
+                // ordered prefix of the tie counts of those waves
+                total = 0;
+                base = 0;
+                unsigned long long rest = wb;
+                while (rest) {
+                    const int ww = __ffsll((long long)rest) - 1;
+                    rest &= rest - 1;
+                    const int cw = __builtin_amdgcn_readlane(c2, ww);
+                    base += (ww < w) ? cw : 0;
+                    total += cw;
+                }
             }
-            if (mw >= 0xF0000000u) {  // nothing left to scan: cannot happen with a free column around
+            if (mg >= 0xF0000000u) {  // nothing left to scan: cannot happen with a free column around
                 bad = true;
                 break;
             }
-            const int bj = jw;
-            const int32_t bd = (int32_t)(mw >> 5);
-            if (!(mw & 16u)) {  // free column reached
+            const int32_t bd = (int32_t)(mg >> 5);
+            const bool mine_d = (m >> 5) == (uint32_t)bd;  // this lane holds a column at the frontier distance
+            if (!(mg & 16u)) {  // a FREE column is at the frontier distance: the search ends there
+                // its index: the lane holding the global minimum key publishes it
+                if (m == mg) s_bj[par][0] = jbase + (int)(m & 15u);
+                __syncthreads();
+                endcol = s_bj[par][0];
                 mind = bd;
-                endcol = bj;
+                par ^= 1;
                 break;
             }
-            const int o = OWN[bj];
-            steps++;
-            {  // finalise column bj in its owner thread; its pending dual change goes into preg
-                const bool mine = (tid == (bj >> 4));
-                switch (bj & 15) {
-#define TD_FIN(k)                                   \
-    case k:                                         \
-        preg[k] = mine ? preg[k] - bd : preg[k];    \
-        key[k] = mine ? (key[k] & 31u) : key[k];    \
-        break;
-                    TD_FIN(0) TD_FIN(1) TD_FIN(2) TD_FIN(3) TD_FIN(4) TD_FIN(5) TD_FIN(6) TD_FIN(7)
-                    TD_FIN(8) TD_FIN(9) TD_FIN(10) TD_FIN(11) TD_FIN(12) TD_FIN(13) TD_FIN(14) TD_FIN(15)
-#undef TD_FIN
+            // every column at the frontier distance is owned: finalise up to SAP_W of them in this
+            // step (ordered by thread) — one memory round trip serves the whole tie class
+            const int nb = total < SAP_W ? total : SAP_W;
+            const unsigned long long myb = __ballot(mine_d);
+            const int rank = base + __popcll(myb & ((1ull << lane) - 1ull));
+            const bool sel = mine_d && rank < SAP_W;
+            {
+                int pe = preg[0];
+#pragma unroll
+                for (int e = 1; e < E; e++) pe = ((m & 15u) == (uint32_t)e) ? preg[e] : pe;
+                if (sel) {
+                    s_bj[par][rank] = jbase + (int)(m & 15u);
+                    s_bp[par][rank] = pe;
                 }
-                sc |= mine ? (1u << (bj & 15)) : 0u;
-            }
-            const uint8_t *rp = shard_row<uint8_t>(tab, o, pitch);
-            const int32_t t1 = bd - ((int32_t)rp[bj] + pw) + 1;  // dist(bj) - row dual of o (+1: key bias)
-            if (has) {
-                const uint4 cv = *reinterpret_cast<const uint4 *>(rp + (size_t)jbase);
-                uint32_t c[E];
-                unpack<uint8_t>(cv, c);
+                // finalise my column: pending dual change goes into preg, key keeps only its low bits
 #pragma unroll
                 for (int e = 0; e < E; e++) {
-                    const uint32_t h1 = (uint32_t)((int32_t)c[e] + preg[e] + t1);
-                    const uint32_t hk = (h1 << 5) | (key[e] & 31u);
-                    const bool better = hk < key[e];
-                    key[e] = better ? hk : key[e];
-                    predr[e] = better ? o : predr[e];
+                    const bool hit = sel && ((m & 15u) == (uint32_t)e);
+                    preg[e] = hit ? preg[e] - bd : preg[e];
+                    key[e] = hit ? (key[e] & 31u) : key[e];
+                }
+                sc |= sel ? (1u << (m & 15u)) : 0u;
+            }
+            __syncthreads();
+            steps += nb;
+            // stream the owners' rows of the batch in groups of SAP_G (that many 16-byte loads in
+            // flight per lane), then relax
+            const int lpar = par;
+            par ^= 1;
+#pragma unroll 1
+            for (int g = 0; g < nb; g += SAP_G) {
+                uint4 cv[SAP_G];
+                int32_t t1[SAP_G];
+                int ob[SAP_G], cs[SAP_G];
+#pragma unroll
+                for (int q = 0; q < SAP_G; q++) {
+                    const int qq = (g + q < nb) ? g + q : g;   // clamp: a duplicate relax is harmless
+                    // wave-uniform values: keep them in SGPRs (scalar addressing, no VGPR cost)
+                    const int bj = __builtin_amdgcn_readfirstlane(s_bj[lpar][qq]);
+                    const int bp = __builtin_amdgcn_readfirstlane(s_bp[lpar][qq]);
+                    const int o = __builtin_amdgcn_readfirstlane(OWN[bj]);
+                    ob[q] = o;
+                    const uint8_t *rp = shard_row<uint8_t>(tab, o, pitch);
+                    cs[q] = (int)rp[bj];       // consumed after ALL loads of the group are issued
+                    t1[q] = bd - bp + 1;       // dist - row dual of o (+1: key bias), minus cs[q] below
+                    if (has) cv[q] = *reinterpret_cast<const uint4 *>(rp + (size_t)jbase);
+                }
+                if (has) {
+#pragma unroll
+                    for (int q = 0; q < SAP_G; q++) {
+                        uint32_t c[E];
+                        unpack<uint8_t>(cv[q], c);
+                        const int32_t tq = t1[q] - __builtin_amdgcn_readfirstlane(cs[q]);
+#pragma unroll
+                        for (int e = 0; e < E; e++) {
+                            const uint32_t h1 = (uint32_t)((int32_t)c[e] + preg[e] + tq);
+                            const uint32_t hk = (h1 << 5) | (key[e] & 31u);
+                            const bool better = hk < key[e];
+                            key[e] = better ? hk : key[e];
+                            predr[e] = better ? ob[q] : predr[e];
+                        }
+                    }
                 }
             }
         }
@@ -1148,8 +1293,8 @@ int sv_compress_t(Solver &sv, bool *fits)
         const int nq = n / 4;
         CT *cc = (CT *)sv.cc.p;
         int32_t *rm = (int32_t *)sv.rowmin.p;
-        if (vec && nq <= 256 * 16) {
-            const int g2 = std::max(1, std::min(nrows, c.n_cu * 4));
+        if (g_creg && vec && nq <= 256 * 16) {
+            const int g2 = std::max(1, std::min(nrows, c.n_cu * g_cgrid));
 #define TD_CR(VPT) k_compress_reg<CT, VPT, 256><<<g2, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl)
             if (nq <= 256) TD_CR(1);
             else if (nq <= 512) TD_CR(2);
@@ -1157,7 +1302,7 @@ int sv_compress_t(Solver &sv, bool *fits)
             else if (nq <= 2048) TD_CR(8);
             else TD_CR(16);
 #undef TD_CR
-        } else if (vec && nq <= 1024 * 16) {
+        } else if (g_creg && vec && nq <= 1024 * 16) {
             k_compress_reg<CT, 16, 1024><<<std::max(1, std::min(nrows, c.n_cu * 2)), 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl);
         } else if (vec)
             k_compress<CT, true><<<grid, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl);
@@ -1217,6 +1362,9 @@ int sv_bid_t(Solver &sv, int r, unsigned long long *keys)
         const int grid = std::min((nrows + 15) / 16, c.n_cu);
         k_bid<CT, true><<<grid, 1024, lds_prices, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
                                                               (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict);
+    } else if (r >= g_row_rounds) {
+        k_bid_row<CT><<<nrows, 256, 0, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
+                                                   (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict);
     } else {
         k_bid<CT, false><<<(nrows + 3) / 4, 256, 0, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
                                                                 (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict);

@@ -24,7 +24,7 @@ import numpy as np
 
 from . import _ffi
 
-DEFAULT_ROUNDS = 16
+DEFAULT_ROUNDS = 12  # same as td_assign (TD_MAX_ROUNDS)
 
 
 def shard_bounds(n, world, rank):
