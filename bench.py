@@ -11,6 +11,9 @@ workload : g1  perf.jl:5 instance family, cost ~ U{10..40}, N = 16384 (BASELINE 
                checked every step.
            g2  greedy_opt.py geometry: positions -> td_cost_build (|a-b|) -> td_assign.
            g3  Simulator.java tick shape: S=50, DROP_TIME threshold, dummy columns.
+           tick BASELINE configs[4]: one Simulator.java tick (n = 1300 cabs x 900 requests):
+               td_cost_build -> td_lcm down to 600 -> shrink -> td_cost_build -> td_assign;
+               value = cabs dispatched per second (n / step time), --n is ignored.
 --gpus N : one process per GPU (torch.distributed, RCCL).  Instances are independent objects:
            every rank solves its own instance (different seed) with no data-path collective —
            weak scaling; value = all instances' assignments / max-over-ranks time.
@@ -38,7 +41,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=16384)
-    ap.add_argument("--workload", default="g1", choices=["g1", "g2", "g3"])
+    ap.add_argument("--workload", default="g1", choices=["g1", "g2", "g3", "tick"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the sharded leg even with one rank (exercises RCCL + the shard API on 1 GPU)")
@@ -47,6 +50,32 @@ def parse():
                          "(BASELINE configs[3]); 0 disables")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     return ap.parse_args()
+
+
+class TickWorkload:
+    """BASELINE configs[4]: the per-tick re-solve of Simulator.java:163-208 with LCM pre-reduce."""
+
+    def __init__(self, seed, td):
+        self.td = td
+        rng = np.random.default_rng(seed)
+        self.n = 1300
+        self.cab_to = rng.integers(0, 50, 1300).astype(np.int32)
+        self.dem_from = rng.integers(0, 50, 900).astype(np.int32)
+        self.expected = None
+        self.kind = "tick"
+
+    def step(self):
+        td = self.td
+        n, cost = td.cost_build(self.cab_to, self.dem_from, None, fill=250000, threshold=10)
+        pairs, lm = td.LCM_simulator(cost, max_non_lcm=600)
+        rows = np.fromiter((p[0] for p in pairs), dtype=np.int64, count=len(pairs))
+        cols = np.fromiter((p[1] for p in pairs), dtype=np.int64, count=len(pairs))
+        keep_c = np.setdiff1d(np.arange(1300), rows)
+        keep_d = np.setdiff1d(np.arange(900), cols)
+        n2, cost2 = td.cost_build(self.cab_to[keep_c], self.dem_from[keep_d], None, fill=250000, threshold=10)
+        r2c, total = td.assign(cost2, n2)
+        self.last = (len(pairs), n2, total)
+        return total
 
 
 class Workload:
@@ -149,10 +178,38 @@ def sharded_extra(n, world, rank, torch, dist, ffi, reps=3):
             "total_cost": int(total), "optimal": bool(total == 10 * n), "scaling": "strong"}
 
 
+def cpu_baseline_tick(seconds):
+    from oracle import oracle
+    rng = np.random.default_rng(1)
+    cab_to = rng.integers(0, 50, 1300)
+    dem_from = rng.integers(0, 50, 900)
+    reps, spent = 0, 0.0
+    t_budget = time.perf_counter() + seconds
+    while True:
+        t0 = time.perf_counter()
+        _, cost = oracle.cost_build(cab_to, dem_from, None, 250000, 10)
+        _, rows, cols, _ = oracle.lcm(cost, mask=250000, stop_value_on=1, stop_value=250000, stop_size=600,
+                                      sum_below=250000, java_scan=1)
+        keep_c = np.setdiff1d(np.arange(1300), rows)
+        keep_d = np.setdiff1d(np.arange(900), cols)
+        _, cost2 = oracle.cost_build(cab_to[keep_c], dem_from[keep_d], None, 250000, 10)
+        tot = oracle.assign(cost2)[0]
+        spent += time.perf_counter() - t0
+        reps += 1
+        if time.perf_counter() + spent / reps > t_budget or reps >= 64:
+            break
+    return {"value": 1300 * reps / spent, "unit": "assignments/s", "cores": 1, "kind": "port",
+            "sample": "%d x (tick: cost build 1300x900 + Java-variant LCM (k full n^2 scans) + cost build + exact "
+                      "solve n=600, oracle/td_oracle.c, one thread), %.1f s" % (reps, spent),
+            "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "last_total": int(tot)}
+
+
 def cpu_baseline(kind, n_gpu, seconds):
     """The oracle's exact solver (a single-thread C port of the path: cost build / generate +
     exact assignment) timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import oracle
+    if kind == "tick":
+        return cpu_baseline_tick(seconds)
     t_budget = time.perf_counter() + seconds
     n = n_gpu
     if kind != "g1":
@@ -235,7 +292,11 @@ def main():
     # run on torch's current stream so that torch events / synchronize bracket our kernels
     ffi.check(ffi.lib().td_set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
-    wl = Workload(args.workload, args.n, 1 + rank, torch, td, ffi)
+    if args.workload == "tick":
+        wl = TickWorkload(1 + rank, td)
+        args.n = wl.n
+    else:
+        wl = Workload(args.workload, args.n, 1 + rank, torch, td, ffi)
 
     def barrier():
         torch.cuda.synchronize()

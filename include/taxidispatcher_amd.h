@@ -162,7 +162,8 @@ TD_API int td_profile_enable(int on);                      /* HIP-event timing p
 TD_API int td_profile_get(int kernel, double *total_ms, int64_t *launches);
 TD_API int td_profile_reset(void);
 /* counters of the last td_assign: [0]=bid rounds, [1]=row scans in bid rounds,
- * [2]=free rows handed to SAP, [3]=SAP dijkstra steps, [4]=cost storage bytes per cell */
+ * [2]=free rows left to the serial finisher, [3]=its dijkstra steps, [4]=cost storage bytes per cell,
+ * [5]=augmentations committed by the parallel finisher */
 TD_API int td_last_stats(int64_t *out, int n);
 
 #ifdef __cplusplus

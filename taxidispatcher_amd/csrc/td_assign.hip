@@ -76,6 +76,7 @@ enum {
     CTL_NFREE = 2,     // rows handed to SAP
     CTL_STEPS = 3,     // SAP dijkstra steps
     CTL_ROUNDS = 4,    // bidding rounds that placed at least one bid
+    CTL_PACC = 5,      // augmentations committed by the parallel finisher
     CTL_PROG = 8,      // [CTL_PROG + r] bids applied in round r
     CTL_WORDS = 8 + 64  // room for up to 48 rounds
 };
@@ -83,7 +84,7 @@ enum {
 constexpr int ROW_BITS = 20;
 
 // tunables (env TD_MAX_ROUNDS / TD_TIE_EVICT / TD_LDS_ROUNDS, read once at td_assign)
-int g_max_rounds = 12, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1, g_row_rounds = 2, g_cgrid = 6, g_creg = 1;
+int g_max_rounds = 12, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1, g_row_rounds = 2, g_cgrid = 6, g_creg = 1, g_psap_batches = 16, g_psap_min = 12, g_psap_u8 = 0;
 void read_tunables()
 {
     static bool done = false;
@@ -96,6 +97,9 @@ void read_tunables()
     if (const char *e = getenv("TD_ROW_ROUNDS")) g_row_rounds = std::max(0, atoi(e));
     if (const char *e = getenv("TD_CGRID")) g_cgrid = std::max(1, atoi(e));
     if (const char *e = getenv("TD_CREG")) g_creg = atoi(e) != 0;
+    if (const char *e = getenv("TD_PSAP")) g_psap_batches = std::max(0, std::min(64, atoi(e)));
+    if (const char *e = getenv("TD_PSAP_MIN")) g_psap_min = std::max(1, atoi(e));
+    if (const char *e = getenv("TD_PSAP_U8")) g_psap_u8 = atoi(e) != 0;
 }
 
 // ---- unpack one 16-byte chunk into E cost values -----------------------------------
@@ -552,13 +556,17 @@ __global__ __launch_bounds__(256) void k_assign(int n, int nrows, int row0, unsi
             const int row = (int)(k & ((1ull << ROW_BITS) - 1)) - 1;
             const PT newp = (PT)(k >> ROW_BITS);
             const int old = owner[j];
+            const PT oldp = pk[j] >> 1;
             // r2c holds this shard's rows only; owner/price are replicated on every shard
             if (old >= row0 && old < row0 + nrows) r2c[old - row0] = -1;
             owner[j] = row;
             if (row >= row0 && row < row0 + nrows) r2c[row - row0] = j;
             pk[j] = (PT)(newp << 1) | (PT)1;
             bid[j] = 0ull;
-            cnt = 1;
+            // progress = a free column got an owner, or a price went up (dual ascent).  A
+            // price-neutral eviction (tie) is not progress: when a round consists only of those,
+            // the rows are cycling through a tie class and the finisher takes over.
+            cnt = (old < 0 || newp > oldp) ? 1 : 0;
         }
     }
     const unsigned long long m = __ballot(cnt);
@@ -597,9 +605,12 @@ __device__ __forceinline__ void wave_argmin(PT &key, int &j, int &o, PT &p)
 {
     if constexpr (sizeof(PT) == 4) {
         const uint32_t m = wave_umin32((uint32_t)key);
-        const unsigned long long b = __ballot((uint32_t)key == m);
+        // among lanes at the minimum key the smallest j wins (deterministic, and lets callers
+        // encode a tie-break in j)
+        const uint32_t jm = wave_umin32(((uint32_t)key == m) ? (uint32_t)j : 0xFFFFFFFFu);
+        const unsigned long long b = __ballot((uint32_t)key == m && (uint32_t)j == jm);
         const int L = __ffsll((long long)b) - 1;
-        j = __builtin_amdgcn_readlane(j, L);
+        j = (int)jm;
         o = __builtin_amdgcn_readlane(o, L);
         p = (PT)__builtin_amdgcn_readlane((int)p, L);
         key = (PT)m;
@@ -1127,6 +1138,304 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
 }
 
 // =====================================================================================
+// Speculative PARALLEL shortest augmenting paths.
+//
+// The serial finisher leaves 255 CUs idle.  Here up to PS_G free rows are searched at the same
+// time, one workgroup each, all against the SAME read-only snapshot (prices, owners).  A search
+// records the columns it finalised (with their distances), its end column and its path.  The
+// commit kernel then accepts a set of searches whose {finalised columns + end column} sets are
+// pairwise disjoint (each column is claimed by the lowest search id with a min; a search is
+// accepted iff it holds every column it touched) and applies their dual updates and path flips.
+// Why disjointness is enough: an accepted search only raises prices of ITS finalised columns and
+// only re-matches rows/columns on ITS path, so (a) the union of the flips is a matching and
+// (b) every matched pair stays tight — a pair in search A's region is tight after A's own update
+// (plain Dijkstra argument on the snapshot) and another search only raises OTHER columns' prices,
+// which cannot lower that row's minimum.  Exact complementary slackness is preserved; rejected
+// rows simply stay free for the next batch (search 0 of a batch is always accepted).
+// Results do not depend on workgroup timing: searches of a batch share one snapshot and the
+// claim is a min over ids.
+// =====================================================================================
+constexpr int PS_G = 192;     // searches per batch
+constexpr int PS_CAP = 768;   // finalised columns recorded per search; longer searches are left to the serial finisher
+
+template <typename PT>
+struct PsRec {
+    int f, endcol, nS, plen, status;  // status 1 = usable
+    int pad[3];
+    PT mind;
+    int S_col[PS_CAP];
+    PT S_d[PS_CAP];
+    int path[PS_CAP + 2];
+};
+
+template <typename CT, bool LDSST>
+__global__ __launch_bounds__(1024) void k_psearch(int n, int nchunks, const ShardTab tab,
+                                                  const typename Tr<CT>::PT *__restrict__ pk,
+                                                  const int *__restrict__ owner_g, int *__restrict__ pred_g,
+                                                  const int *__restrict__ list, const int *__restrict__ ctl,
+                                                  PsRec<typename Tr<CT>::PT> *__restrict__ recs)
+{
+    using PT = typename Tr<CT>::PT;
+    constexpr int E = Tr<CT>::E;
+    constexpr PT KMAX = Tr<CT>::KMAX;
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ PT s_rk[2][16];
+    __shared__ PT s_rp[2][16];
+    __shared__ int s_rj[2][16];
+    __shared__ int s_ro[2][16];
+    const int nfree = ctl[CTL_NFREE];
+    const int b = blockIdx.x;
+    if (b >= nfree) return;
+    const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
+    const int npad = nchunks * E;
+    const size_t pitch = (size_t)npad;
+    int *OWN = LDSST ? reinterpret_cast<int *>(smem) : nullptr;
+    int *PRED = LDSST ? reinterpret_cast<int *>(smem + (size_t)npad * sizeof(int)) : pred_g + (size_t)b * npad;
+    PsRec<PT> *rec = recs + b;
+    // searches of a batch are spread evenly over the (row-ordered) free list: neighbouring rows
+    // tend to want the same columns (cabs at one stand) and would only reject each other
+    const int gact = nfree < (int)gridDim.x ? nfree : (int)gridDim.x;
+    const int f = list[(int)(((long long)b * nfree) / gact)];
+    // Ties (equal distance, same owned bit) are broken by a column order rotated per search:
+    // with the plain lowest-index rule every search of a batch would end in the same free
+    // column of a tie class and all but one would be rejected.
+    const int rot = (int)(((uint64_t)(((uint32_t)f + 1u) * 0x9E3779B1u) * (uint64_t)npad) >> 32);
+    if (LDSST) {
+        for (int j = tid; j < npad; j += T) OWN[j] = owner_g[j];
+        __syncthreads();
+    }
+    const bool has = tid < nchunks;
+    const int jbase = tid * E;
+    PT d[E], preg[E];
+    int ownr[E];
+    uint32_t scanned = 0, owned = 0, valid = 0;
+    {
+        uint32_t c[E];
+        if (has) {
+            const uint4 cv = *reinterpret_cast<const uint4 *>(shard_row<CT>(tab, f, pitch) + (size_t)jbase);
+            unpack<CT>(cv, c);
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int j = jbase + e;
+            const bool ok = has && j < n;
+            const PT p = ok ? (PT)(pk[j] >> 1) : (PT)0;
+            const int o = ok ? (LDSST ? OWN[j] : owner_g[j]) : -2;
+            preg[e] = p;
+            ownr[e] = o;
+            d[e] = ok ? (PT)c[e] + p : (KMAX >> 2);
+            if (ok) {
+                valid |= 1u << e;
+                PRED[j] = -1;
+            }
+            if (o != -1) owned |= 1u << e;
+        }
+    }
+    int steps = 0, par = 0, endcol = -1, status = 1;
+    PT mind = 0;
+    for (int guard = 0; guard <= npad; guard++) {
+        PT bk = KMAX, bp = 0;
+        int bj = INT_MAX, bo = -2;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const bool ok = ((valid >> e) & 1u) && !((scanned >> e) & 1u);
+            const PT v = (PT)(d[e] << 1) | (PT)((owned >> e) & 1u);
+            int jr = jbase + e - rot;
+            jr += (jr < 0) ? npad : 0;
+            if (ok && (v < bk || (v == bk && jr < bj))) {
+                bk = v;
+                bj = jr;  // rotated index while reducing
+                bo = ownr[e];
+                bp = preg[e];
+            }
+        }
+        wave_argmin<PT>(bk, bj, bo, bp);
+        if (nw > 1) {
+            if (lane == 0) {
+                s_rk[par][w] = bk;
+                s_rj[par][w] = bj;
+                s_ro[par][w] = bo;
+                s_rp[par][w] = bp;
+            }
+            __syncthreads();
+            const bool hv = lane < nw;
+            bk = hv ? s_rk[par][lane] : KMAX;
+            bj = hv ? s_rj[par][lane] : INT_MAX;
+            bo = hv ? s_ro[par][lane] : -2;
+            bp = hv ? s_rp[par][lane] : (PT)0;
+            wave_argmin<PT>(bk, bj, bo, bp);
+            par ^= 1;
+        }
+        if (bj == INT_MAX) {
+            status = 0;
+            break;
+        }
+        bj += rot;  // back to the column index
+        bj -= (bj >= npad) ? npad : 0;
+        const PT bd = bk >> 1;
+        if (!(bk & 1)) {
+            mind = bd;
+            endcol = bj;
+            break;
+        }
+        if (steps >= PS_CAP) {  // too long for a speculative record
+            status = 0;
+            break;
+        }
+        if (tid == 0) {
+            rec->S_col[steps] = bj;
+            rec->S_d[steps] = bd;
+        }
+        steps++;
+        if (tid == (bj / E)) scanned |= 1u << (bj - (bj / E) * E);
+        const CT *rp = shard_row<CT>(tab, bo, pitch);
+        const PT wstar = (PT)rp[bj] + bp;
+        if (has) {
+            const uint4 cv = *reinterpret_cast<const uint4 *>(rp + (size_t)jbase);
+            uint32_t c[E];
+            unpack<CT>(cv, c);
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const PT h = bd + ((PT)c[e] + preg[e] - wstar);
+                const bool ok = ((valid >> e) & 1u) && !((scanned >> e) & 1u);
+                if (ok && h < d[e]) {
+                    d[e] = h;
+                    PRED[jbase + e] = bj;  // predecessor COLUMN (the path walk then needs no row->col map)
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int plen = 0;
+        if (status == 1 && endcol >= 0) {
+            int j = endcol;
+            while (j >= 0 && plen <= PS_CAP) {
+                rec->path[plen++] = j;
+                j = PRED[j];
+            }
+            if (j >= 0) status = 0;
+        } else
+            status = 0;
+        rec->f = f;
+        rec->endcol = endcol;
+        rec->nS = steps;
+        rec->plen = plen;
+        rec->mind = mind;
+        rec->status = status;
+    }
+}
+
+// commit of one batch + rebuild of the ordered free-row list.  One workgroup.
+//
+// Acceptance (deterministic, order = search id r):
+//   touch[col] = min id over searches that finalised col or have it on their path
+//   pthm[col]  = min id over searches that have col on their path
+//   r is accepted  <=>  every path column of r has touch == r   (nobody else touches r's path)
+//                  and  every finalised column of r has pthm >= r (r touches nobody's path...
+//                       a higher id with that column on its path fails its own first test)
+// Two accepted searches may share finalised-only columns; such a column is raised by the MAX of
+// the two raises (mind - d): each search's Dijkstra guarantees reduced costs >= its own raise,
+// so the max keeps every reduced cost >= 0, and columns on an accepted path are touched by that
+// search alone, so its path stays exactly tight.
+template <typename PT>
+__global__ __launch_bounds__(1024) void k_pcommit(int n, PT *__restrict__ pk, int *__restrict__ owner, int *__restrict__ r2c,
+                                                  int *__restrict__ list, int *__restrict__ ctl,
+                                                  unsigned long long *__restrict__ raise,  // n words, all zero on entry/exit
+                                                  const PsRec<PT> *__restrict__ recs, int first)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    int *touch = reinterpret_cast<int *>(smem);  // n ints
+    int *pthm = touch + n;                       // n ints
+    __shared__ int s_wcnt[16];
+    __shared__ int s_nfree;
+    __shared__ int s_acc;
+    const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
+    const int nres = first ? 0 : min(ctl[CTL_NFREE], PS_G);
+    if (!first && nres == 0) return;
+    for (int j = tid; j < n; j += T) {
+        touch[j] = INT_MAX;
+        pthm[j] = INT_MAX;
+    }
+    if (tid == 0) s_acc = 0;
+    __syncthreads();
+    // phase 1: claims
+    for (int r = w; r < nres; r += nw) {
+        const PsRec<PT> *rc = recs + r;
+        if (rc->status != 1) continue;
+        for (int k = lane; k < rc->nS; k += 64) atomicMin(&touch[rc->S_col[k]], r);
+        for (int k = lane; k < rc->plen; k += 64) {
+            atomicMin(&touch[rc->path[k]], r);
+            atomicMin(&pthm[rc->path[k]], r);
+        }
+    }
+    __syncthreads();
+    // phase 2: accepted searches post their raises and flip their path
+    for (int r = w; r < nres; r += nw) {
+        const PsRec<PT> *rc = recs + r;
+        if (rc->status != 1) continue;
+        bool ok = true;
+        for (int k = lane; k < rc->plen; k += 64) ok = ok && (touch[rc->path[k]] == r);
+        for (int k = lane; k < rc->nS; k += 64) ok = ok && (pthm[rc->S_col[k]] >= r);
+        if (__ballot(!ok)) continue;
+        const PT mind = rc->mind;
+        for (int k = lane; k < rc->nS; k += 64) {
+            const PT dv = mind - rc->S_d[k];
+            if (dv > 0) atomicMax(&raise[rc->S_col[k]], (unsigned long long)dv);
+        }
+        if (lane == 0) {
+            // path[0] = end column, path[i+1] = predecessor column of path[i]; the row that takes
+            // path[i] is the (old) owner of path[i+1], and the root row takes the last one
+            const int pl = rc->plen;
+            for (int i = 0; i < pl; i++) {
+                const int col = rc->path[i];
+                const int row = (i + 1 < pl) ? owner[rc->path[i + 1]] : rc->f;
+                owner[col] = row;
+                r2c[row] = col;
+            }
+            atomicAdd(&s_acc, 1);
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    // phase 2b: apply the raises (max over the accepted searches) and refresh the owned bits
+    for (int j = tid; j < n; j += T) {
+        const unsigned long long rv = __hip_atomic_load(&raise[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        PT p = pk[j] >> 1;
+        if (rv) {
+            p += (PT)rv;
+            raise[j] = 0ull;
+        }
+        pk[j] = (PT)(p << 1) | (PT)(owner[j] >= 0 ? 1 : 0);
+    }
+    // phase 3: ordered list of the rows that are still free
+    if (tid == 0) s_nfree = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < n; r0 += T) {
+        const int r = r0 + tid;
+        const bool fr = r < n && r2c[r] < 0;
+        const unsigned long long m = __ballot(fr);
+        if (lane == 0) s_wcnt[w] = __popcll(m);
+        __syncthreads();
+        int base = s_nfree;
+        for (int k = 0; k < w; k++) base += s_wcnt[k];
+        if (fr) list[base + __popcll(m & ((1ull << lane) - 1ull))] = r;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int k = 0; k < nw; k++) tot += s_wcnt[k];
+            s_nfree += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        // nothing accepted (every search overflowed): stop launching useful work for later batches
+        ctl[CTL_NFREE] = (!first && s_acc == 0) ? 0 : s_nfree;
+        ctl[CTL_PACC] += s_acc;
+    }
+}
+
+// =====================================================================================
 // k_final: total from the original costs + permutation check; k_dual: LP bound
 // =====================================================================================
 __global__ __launch_bounds__(256) void k_final(int n, int nrows, int row0, const int32_t *__restrict__ cost,
@@ -1234,10 +1543,10 @@ struct td_shard {
     int bpc = 0;  // bytes per stored cell: 1, 2, 4 (0 = not compressed yet)
     int nchunks = 0, npad = 0;
     const int32_t *d_cost = nullptr;  // nrows x n, device
-    Buf stage, cc, price, owner, r2c, r2c_full, bid, pred, list, rowmin, misc;
+    Buf stage, cc, price, owner, r2c, r2c_full, bid, pred, list, rowmin, misc, psrec;
     void free_all()
     {
-        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &misc};
+        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &misc, &psrec};
         for (Buf *b : bs) {
             if (b->p) (void)hipFree(b->p);
             b->p = nullptr;
@@ -1411,6 +1720,37 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
     const size_t shm = lds ? st : 0;
     if (CH * E > 64) return fail(TD_ERANGE, "n=%d too large for the single-workgroup finisher", n);
     ProfScope ps(TD_K_SAP);
+    // ---- speculative parallel searches first (a few batches), the serial workgroup mops up
+    // (u8 instances go straight to the lean tie-batching serial workgroup, which is faster there)
+    if (g_psap_batches > 0 && CH == 1 && lds && n >= 64 && (sizeof(CT) > 1 || g_psap_u8)) {
+        Ctx &c = ctx();
+        using PT = typename Tr<CT>::PT;
+        int rc = ensure(sv.psrec, sizeof(PsRec<PT>) * (size_t)PS_G);
+        if (rc) return rc;
+        PsRec<PT> *recs = (PsRec<PT> *)sv.psrec.p;
+        const size_t cshm = 2 * sizeof(int) * (size_t)n;
+        if (shm > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_psearch<CT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (cshm > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_pcommit<PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cshm);
+        unsigned long long *raise = (unsigned long long *)sv.bid.p;  // all zero after the bidding rounds
+        k_pcommit<PT><<<1, 1024, cshm, c.stream>>>(n, (PT *)sv.price.p, (int *)sv.owner.p, r2c_full, (int *)sv.list.p,
+                                                   (int *)sv.misc.p, raise, recs, 1);
+        // one small read-back decides how many speculative batches are worth launching: with a
+        // handful of free rows the serial (tie-batching) workgroup is faster than any batch
+        TD_HIP(hipMemcpyAsync(c.pinned, (int *)sv.misc.p + CTL_NFREE, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipStreamSynchronize(c.stream));
+        const int nfree0 = ((int *)c.pinned)[0];
+        int batches = 0;
+        if (nfree0 >= g_psap_min) batches = std::min(g_psap_batches, (nfree0 + 31) / 32);
+        for (int b = 0; b < batches; b++) {
+            k_psearch<CT, true><<<PS_G, T, shm, c.stream>>>(n, nchunks, tab, (const PT *)sv.price.p, (const int *)sv.owner.p,
+                                                           (int *)sv.pred.p, (const int *)sv.list.p, (const int *)sv.misc.p, recs);
+            k_pcommit<PT><<<1, 1024, cshm, c.stream>>>(n, (PT *)sv.price.p, (int *)sv.owner.p, r2c_full, (int *)sv.list.p,
+                                                       (int *)sv.misc.p, raise, recs, 0);
+        }
+        TD_HIP(hipGetLastError());
+    }
     if constexpr (sizeof(CT) == 1) {
         if (CH == 1 && g_sap8) {
             Ctx &c = ctx();
@@ -1489,11 +1829,17 @@ int sv_readback(Solver &sv, int64_t *total, int64_t *dual, int max_rounds)
     int rounds = 0;
     for (int r = 0; r < max_rounds && r < 48; r++)
         if (hctl[CTL_PROG + r] > 0) rounds++;
+    if (getenv("TD_DEBUG")) {
+        fprintf(stderr, "[td] n=%d bpc=%d progress per round:", sv.n, sv.bpc);
+        for (int r = 0; r < max_rounds && r < 48; r++) fprintf(stderr, " %d", hctl[CTL_PROG + r]);
+        fprintf(stderr, " | parallel-sap %d | serial-sap rows %d steps %d\n", hctl[CTL_PACC], hctl[CTL_NFREE], hctl[CTL_STEPS]);
+    }
     c.stats[0] = rounds;
     c.stats[1] = 0;
     c.stats[2] = hctl[CTL_NFREE];
     c.stats[3] = hctl[CTL_STEPS];
     c.stats[4] = sv.bpc;
+    c.stats[5] = hctl[CTL_PACC];
     return TD_OK;
 }
 

@@ -31,12 +31,20 @@ __device__ __forceinline__ unsigned long long lcm_scan_row(const int32_t *__rest
                                                            const uint32_t *colmask, int64_t cand_limit)
 {
     unsigned long long best = LCM_INF;
-    for (int j = lane; j < n; j += 64) {
-        const int32_t v = rp[j];
-        const bool masked = colmask ? ((colmask[j >> 5] >> (j & 31)) & 1u) : false;
-        if (!masked && (int64_t)v < cand_limit) {
-            const unsigned long long k = lcm_key(v, j);
-            best = k < best ? k : best;
+    for (int j0 = lane; j0 < n; j0 += 256) {
+        int32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = (j0 + 64 * u < n) ? rp[j0 + 64 * u] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + 64 * u;
+            if (j < n) {
+                const bool masked = colmask ? ((colmask[j >> 5] >> (j & 31)) & 1u) : false;
+                if (!masked && (int64_t)v[u] < cand_limit) {
+                    const unsigned long long k = lcm_key(v[u], j);
+                    best = k < best ? k : best;
+                }
+            }
         }
     }
 #pragma unroll
@@ -66,15 +74,21 @@ struct LcmOut {
 __global__ __launch_bounds__(1024) void k_lcm_loop(int n, const int32_t *__restrict__ cost, int64_t cand_limit,
                                                    int32_t mask, int32_t threshold, int stop_value_on,
                                                    int32_t stop_value, int stop_size, int64_t sum_below, int max_pairs,
-                                                   unsigned long long *__restrict__ rowbest, int32_t *__restrict__ rows,
+                                                   unsigned long long *__restrict__ rowbest, int rb_in_lds,
+                                                   int32_t *__restrict__ rows,
                                                    int32_t *__restrict__ cols, int *__restrict__ rescan,
                                                    LcmOut *__restrict__ out)
 {
-    extern __shared__ uint32_t s_colmask[];  // (n+31)/32 words
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    // dynamic LDS: [rowbest copy: n x 8 B when it fits] [column mask: (n+31)/32 words]
+    unsigned long long *rb = rb_in_lds ? reinterpret_cast<unsigned long long *>(s_dyn) : rowbest;
+    uint32_t *s_colmask = reinterpret_cast<uint32_t *>(s_dyn + (rb_in_lds ? (size_t)n * 8 : 0));
     __shared__ unsigned long long s_red[16];
     __shared__ int s_nres;
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
     for (int k = tid; k < (n + 31) / 32; k += T) s_colmask[k] = 0u;
+    if (rb_in_lds)
+        for (int i = tid; i < n; i += T) rb[i] = rowbest[i];
     if (tid == 0) s_nres = 0;
     __syncthreads();
     int npairs = 0, size = n;
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(1024) void k_lcm_loop(int n, const int32_t *__restr
         // block argmin over (value, row); the column rides along in the row's cached key
         unsigned long long best = LCM_INF;
         for (int i = tid; i < n; i += T) {
-            const unsigned long long k = rowbest[i];
+            const unsigned long long k = rb[i];
             if (k != LCM_INF) {
                 const unsigned long long kk = (k & 0xFFFFFFFF00000000ull) | (uint32_t)i;
                 best = kk < best ? kk : best;
@@ -106,7 +120,7 @@ __global__ __launch_bounds__(1024) void k_lcm_loop(int n, const int32_t *__restr
         }
         const int r = (int)(uint32_t)best;
         const int32_t v = lcm_val(best);
-        const int c = (int)(uint32_t)rowbest[r];
+        const int c = (int)(uint32_t)rb[r];
         last_min = v;
         if (threshold >= 0 && v > threshold) break;       // greedy_opt.py:68-69
         if (stop_value_on && v >= stop_value) break;       // Simulator.java:538
@@ -118,9 +132,9 @@ __global__ __launch_bounds__(1024) void k_lcm_loop(int n, const int32_t *__restr
         npairs++;
         if ((int64_t)v < sum_below) total += v;
         size--;
-        __syncthreads();  // everyone has read rowbest[r] / s_red
+        __syncthreads();  // everyone has read rb[r] / s_red
         if (tid == 0) {
-            rowbest[r] = LCM_INF;
+            rb[r] = LCM_INF;
             s_colmask[c >> 5] |= 1u << (c & 31);
             s_nres = 0;
         }
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(1024) void k_lcm_loop(int n, const int32_t *__restr
         if (stop_size >= 0 && size == stop_size) break;    // Simulator.java:544-545
         // rows whose cached first minimum sat in column c must be re-scanned
         for (int i = tid; i < n; i += T) {
-            const unsigned long long k = rowbest[i];
+            const unsigned long long k = rb[i];
             if (k != LCM_INF && (int)(uint32_t)k == c) rescan[atomicAdd(&s_nres, 1)] = i;
         }
         __syncthreads();
@@ -136,7 +150,7 @@ __global__ __launch_bounds__(1024) void k_lcm_loop(int n, const int32_t *__restr
         for (int q = w; q < nres; q += nw) {
             const int i = rescan[q];
             const unsigned long long b = lcm_scan_row(cost + (int64_t)i * n, n, lane, s_colmask, cand_limit);
-            if (lane == 0) rowbest[i] = b;
+            if (lane == 0) rb[i] = b;
         }
         __syncthreads();
     }
@@ -173,14 +187,18 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
     int32_t *d_rows = (int32_t *)c.lcm_b.p, *d_cols = d_rows + n;
     // Java's scan only ever sees cells strictly below big_cost (Simulator.java:529-537)
     const int64_t cand_limit = stop_value_on ? (int64_t)stop_value : (int64_t)INT64_MAX;
-    const size_t shm = sizeof(uint32_t) * (size_t)((n + 31) / 32);
+    const size_t shm_mask = sizeof(uint32_t) * (size_t)((n + 31) / 32);
     {
         ProfScope ps(TD_K_LCM);
         k_lcm_rowscan<<<std::min((n + 3) / 4, c.n_cu * 8), 256, 0, c.stream>>>(n, d_cost, cand_limit,
                                                                                (unsigned long long *)c.lcm_a.p);
         int T = std::min(1024, std::max(64, ((n + 63) / 64) * 64));
+        const int rb_in_lds = ((size_t)n * 8 + shm_mask) <= 96 * 1024;
+        const size_t shm = shm_mask + (rb_in_lds ? (size_t)n * 8 : 0);
+        if (shm > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_lcm_loop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         k_lcm_loop<<<1, T, shm, c.stream>>>(n, d_cost, cand_limit, mask, threshold, stop_value_on, stop_value,
-                                            stop_size, sum_below, cap, (unsigned long long *)c.lcm_a.p, d_rows, d_cols,
+                                            stop_size, sum_below, cap, (unsigned long long *)c.lcm_a.p, rb_in_lds, d_rows, d_cols,
                                             (int *)c.lcm_c.p, (LcmOut *)c.lcm_d.p);
     }
     TD_HIP(hipGetLastError());

@@ -23,7 +23,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps({"n": n, "ms": round(dt * 1e3, 3), "total": tot, "ok": tot == 10 * n == dual, "stats": td.last_stats(), "prof": prof}))
     sys.exit(0)
 for n in [16384]:
-    for env in [{}, {"TD_CGRID": "2"}, {"TD_CGRID": "6"}, {"TD_CGRID": "8"}, {"TD_CGRID": "16"}, {"TD_CGRID": "64"}, {"TD_CREG": "0"}]:
+    for env in [{}, {"TD_PSAP": "0"}, {"TD_PSAP": "1"}, {"TD_PSAP": "2"}, {"TD_PSAP": "16"}]:
         e = dict(os.environ); e.update(env)
         out = subprocess.run([sys.executable, __file__, "child", str(n)], env=e, capture_output=True, text=True)
         print(env, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-500:], flush=True)
