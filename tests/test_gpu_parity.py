@@ -304,3 +304,35 @@ def test_large_properties(td):
     td.cost_build(a, b, None, fill=BIG, threshold=-1, out=ct)
     r2c, total, dual = td.assign(ct, n, want_dual=True)
     assert total == int(np.abs(np.sort(a) - np.sort(b)).sum()) == dual
+
+
+def test_randomized_differential(td):
+    """300 random small instances: random size, value range, sign, tie density, big_cost
+    sentinels and unbalanced padding — total and certificate against the oracle."""
+    rng = np.random.default_rng(20201)
+    for it in range(300):
+        n = int(rng.integers(1, 90))
+        mode = it % 6
+        if mode == 0:
+            c = rng.integers(0, int(rng.integers(1, 6)), (n, n))                   # dense ties
+        elif mode == 1:
+            c = rng.integers(-10**int(rng.integers(1, 9)), 10**int(rng.integers(1, 9)), (n, n))
+        elif mode == 2:
+            c = rng.integers(0, 10, (n, n))
+            c[rng.random((n, n)) < 0.6] = BIG                                     # thresholded cells
+        elif mode == 3:
+            ns = int(rng.integers(1, n + 1))
+            c = np.full((n, n), BIG)
+            c[:ns, :] = rng.integers(0, 50, (ns, n))                              # dummy rows
+        elif mode == 4:
+            a, b = rng.integers(0, 50, n), rng.integers(0, 50, n)
+            c = np.abs(a[:, None] - b[None, :])                                   # stand geometry
+        else:
+            c = rng.integers(0, 70000, (n, n))
+            c[:, : n // 2] //= 1000                                               # mixed widths per column
+        c = c.astype(np.int32)
+        r2c, total, dual = td.assign(c, want_dual=True)
+        ref = oracle.assign(c)[0]
+        assert total == ref == dual, (it, n, mode, total, ref, dual)
+        assert sorted(r2c.tolist()) == list(range(n))
+        assert int(c[np.arange(n), r2c].astype(np.int64).sum()) == total
