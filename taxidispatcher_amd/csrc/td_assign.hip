@@ -77,6 +77,7 @@ enum {
     CTL_STEPS = 3,     // SAP dijkstra steps
     CTL_ROUNDS = 4,    // bidding rounds that placed at least one bid
     CTL_PACC = 5,      // augmentations committed by the parallel finisher
+    CTL_RANGE = 6,     // [6..7] 64-bit max row range seen by a compress pass that did not fit
     CTL_PROG = 8,      // [CTL_PROG + r] bids applied in round r
     CTL_WORDS = 8 + 64  // room for up to 48 rounds
 };
@@ -84,7 +85,7 @@ enum {
 constexpr int ROW_BITS = 20;
 
 // tunables (env TD_MAX_ROUNDS / TD_TIE_EVICT / TD_LDS_ROUNDS, read once at td_assign)
-int g_max_rounds = 12, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1, g_row_rounds = 2, g_cgrid = 6, g_creg = 1, g_psap_batches = 16, g_psap_min = 12, g_psap_u8 = 0;
+int g_max_rounds = 12, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1, g_row_rounds = 2, g_cgrid = 6, g_creg = 1, g_psap_batches = 16, g_psap_min = 12, g_psap_u8 = 0, g_speculate = 1;
 void read_tunables()
 {
     static bool done = false;
@@ -100,6 +101,7 @@ void read_tunables()
     if (const char *e = getenv("TD_PSAP")) g_psap_batches = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("TD_PSAP_MIN")) g_psap_min = std::max(1, atoi(e));
     if (const char *e = getenv("TD_PSAP_U8")) g_psap_u8 = atoi(e) != 0;
+    if (const char *e = getenv("TD_SPECULATE")) g_speculate = atoi(e) != 0;
 }
 
 // ---- unpack one 16-byte chunk into E cost values -----------------------------------
@@ -186,7 +188,10 @@ __global__ __launch_bounds__(256) void k_compress(int n, int nrows, int nchunks,
         __syncthreads();
         if (tid == 0) {
             rowmin[row] = mn;
-            if ((int64_t)mx - (int64_t)mn > Tr<CT>::LIMIT) atomicOr(&ctl[CTL_FLAG], 1);
+            if ((int64_t)mx - (int64_t)mn > Tr<CT>::LIMIT) {
+                atomicOr(&ctl[CTL_FLAG], 1);
+                atomicMax(reinterpret_cast<unsigned long long *>(&ctl[CTL_RANGE]), (unsigned long long)((int64_t)mx - (int64_t)mn));
+            }
         }
         // second read of the row comes from L2 (the workgroup has just streamed it)
         CT *dst = cc + (size_t)row * pitch;
@@ -279,7 +284,10 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nrows, int 
         par ^= 1;
         if (tid == 0) {
             rowmin[row] = mn;
-            if ((int64_t)mx - (int64_t)mn > Tr<CT>::LIMIT) atomicOr(&ctl[CTL_FLAG], 1);
+            if ((int64_t)mx - (int64_t)mn > Tr<CT>::LIMIT) {
+                atomicOr(&ctl[CTL_FLAG], 1);
+                atomicMax(reinterpret_cast<unsigned long long *>(&ctl[CTL_RANGE]), (unsigned long long)((int64_t)mx - (int64_t)mn));
+            }
         }
         CT *dst = cc + (size_t)row * pitch;
 #pragma unroll
@@ -316,7 +324,7 @@ __global__ void k_init_state(int n, int npad, int nrows, PT *pk, PT padkey, int 
         owner[j] = (j < n) ? -1 : -2;
     }
     if (j < nrows) r2c[j] = -1;
-    if (j < CTL_WORDS && j != CTL_FLAG) ctl[j] = 0;
+    if (j < CTL_WORDS && j != CTL_FLAG && j != CTL_RANGE && j != CTL_RANGE + 1) ctl[j] = 0;
 }
 
 // =====================================================================================
@@ -334,6 +342,7 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nrows, int
     constexpr int E = Tr<CT>::E;
     constexpr int U = 4;  // 16-byte row chunks in flight per lane
     extern __shared__ __align__(16) unsigned char smem[];
+    if (ctl[CTL_FLAG]) return;  // speculated storage width did not fit: the host redoes the solve
     if (round > 0 && ctl[CTL_PROG + round - 1] == 0) return;  // previous round placed no bid: converged
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const size_t pitch = (size_t)nchunks * E;
@@ -452,6 +461,7 @@ __global__ __launch_bounds__(256) void k_bid_row(int n, int nrows, int row0, int
     constexpr int U = 4;
     __shared__ PT s_k[4], s_x[4];
     __shared__ int s_p[4];
+    if (ctl[CTL_FLAG]) return;
     if (round > 0 && ctl[CTL_PROG + round - 1] == 0) return;
     const int lrow = blockIdx.x;
     if (lrow >= nrows || r2c[lrow] >= 0) return;
@@ -547,6 +557,7 @@ __global__ __launch_bounds__(256) void k_assign(int n, int nrows, int row0, unsi
                                                 PT *__restrict__ pk, int *__restrict__ owner, int *__restrict__ r2c,
                                                 int *__restrict__ ctl, int round)
 {
+    if (ctl[CTL_FLAG]) return;
     if (round > 0 && ctl[CTL_PROG + round - 1] == 0) return;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     int cnt = 0;
@@ -670,6 +681,7 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab
     __shared__ int s_wcnt[16];
     __shared__ int s_nfree;
 
+    if (ctl[CTL_FLAG]) return;
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
     const int npad = nchunks * E;
     const size_t pitch = (size_t)npad;
@@ -918,6 +930,7 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
     __shared__ int s_wcnt[16];
     __shared__ int s_nfree;
 
+    if (ctl[CTL_FLAG]) return;
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
     const int npad = nchunks * E;
     const size_t pitch = (size_t)npad;
@@ -1156,7 +1169,7 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
 // claim is a min over ids.
 // =====================================================================================
 constexpr int PS_G = 192;     // searches per batch
-constexpr int PS_CAP = 768;   // finalised columns recorded per search; longer searches are left to the serial finisher
+constexpr int PS_CAP = 4096;  // finalised columns recorded per search; longer searches are left to the serial finisher
 
 template <typename PT>
 struct PsRec {
@@ -1442,6 +1455,7 @@ __global__ __launch_bounds__(256) void k_final(int n, int nrows, int row0, const
                                                const int *__restrict__ r2c, const int *__restrict__ owner,
                                                unsigned long long *__restrict__ out, int *__restrict__ ctl)
 {
+    if (ctl[CTL_FLAG]) return;
     long long s = 0;
     int bad = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += gridDim.x * blockDim.x) {
@@ -1585,7 +1599,7 @@ int sv_prepare(Solver &sv, int n, int row0, int nrows, const int32_t *cost)
 }
 
 template <typename CT>
-int sv_compress_t(Solver &sv, bool *fits)
+int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
 {
     Ctx &c = ctx();
     constexpr int E = Tr<CT>::E;
@@ -1594,7 +1608,7 @@ int sv_compress_t(Solver &sv, bool *fits)
     int rc;
     if ((rc = ensure(sv.cc, std::max<size_t>((size_t)nrows * nchunks * 16, 256)))) return rc;
     int *ctl = (int *)sv.misc.p;
-    TD_HIP(hipMemsetAsync(ctl, 0, sizeof(int), c.stream));
+    TD_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(int), c.stream));  // flag, error, stats, range
     const bool vec = (n % 4 == 0) && (((uintptr_t)sv.d_cost & 15) == 0);
     const int grid = std::max(1, std::min(nrows, c.n_cu * 8));
     if (nrows > 0) {
@@ -1619,9 +1633,15 @@ int sv_compress_t(Solver &sv, bool *fits)
             k_compress<CT, false><<<grid, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl);
     }
     TD_HIP(hipGetLastError());
-    TD_HIP(hipMemcpyAsync(c.pinned, ctl, sizeof(int), hipMemcpyDeviceToHost, c.stream));
-    TD_HIP(hipStreamSynchronize(c.stream));
-    *fits = (((int *)c.pinned)[0] == 0);
+    if (speculate) {
+        // do not stall the stream on the "row range fits" flag: carry on as if it fits; the flag
+        // comes back with the final read-back and a wrong guess is simply redone one width up
+        *fits = true;
+    } else {
+        TD_HIP(hipMemcpyAsync(c.pinned, ctl, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipStreamSynchronize(c.stream));
+        *fits = (((int *)c.pinned)[0] == 0);
+    }
     if (*fits) {
         sv.bpc = (int)sizeof(CT);
         sv.nchunks = nchunks;
@@ -1630,12 +1650,12 @@ int sv_compress_t(Solver &sv, bool *fits)
     return TD_OK;
 }
 
-int sv_compress(Solver &sv, int bpc, bool *fits)
+int sv_compress(Solver &sv, int bpc, bool *fits, bool speculate = false)
 {
     switch (bpc) {
-        case 1: return sv_compress_t<uint8_t>(sv, fits);
-        case 2: return sv_compress_t<uint16_t>(sv, fits);
-        case 4: return sv_compress_t<uint32_t>(sv, fits);
+        case 1: return sv_compress_t<uint8_t>(sv, fits, speculate);
+        case 2: return sv_compress_t<uint16_t>(sv, fits, speculate);
+        case 4: return sv_compress_t<uint32_t>(sv, fits, speculate);
     }
     return fail(TD_EINVAL, "bytes per cell must be 1, 2 or 4");
 }
@@ -1815,7 +1835,7 @@ int sv_totals_t(Solver &sv, bool want_dual)
     } while (0)
 
 // read back ctl + totals (one sync)
-int sv_readback(Solver &sv, int64_t *total, int64_t *dual, int max_rounds)
+int sv_readback(Solver &sv, int64_t *total, int64_t *dual, int max_rounds, int *range_flag = nullptr)
 {
     Ctx &c = ctx();
     char *pin = (char *)c.pinned;
@@ -1823,6 +1843,13 @@ int sv_readback(Solver &sv, int64_t *total, int64_t *dual, int max_rounds)
     TD_HIP(hipMemcpyAsync(pin + 1024, (char *)sv.misc.p + 1024, 16, hipMemcpyDeviceToHost, c.stream));
     TD_HIP(hipStreamSynchronize(c.stream));
     const int *hctl = (const int *)pin;
+    if (range_flag) {
+        *range_flag = hctl[CTL_FLAG];
+        if (*range_flag) {  // the speculated storage width was too narrow: caller retries
+            c.stats[6] = (int64_t)(((const unsigned long long *)(hctl + CTL_RANGE))[0]);
+            return TD_OK;
+        }
+    }
     if (hctl[CTL_ERR]) return fail(TD_EINTERNAL, "device-side consistency check failed (code %d)", hctl[CTL_ERR]);
     if (total) *total = ((const int64_t *)(pin + 1024))[0];
     if (dual) *dual = ((const int64_t *)(pin + 1024))[1];
@@ -1879,30 +1906,42 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         if (dual_bound) *dual_bound = dual;
         return TD_OK;
     }
-    bool fits = false;
-    for (int bpc : {1, 2, 4}) {
-        if ((rc = sv_compress(sv, bpc, &fits))) return rc;
-        if (fits) break;
-    }
-    if (!fits) return fail(TD_ERANGE, "row cost range exceeds 2^32-2");
-    TD_DISPATCH(sv, sv_begin_t, sv);
-    if (rc) return rc;
     const int max_rounds = g_max_rounds;
-    for (int r = 0; r < max_rounds; r++) {
-        TD_DISPATCH(sv, sv_bid_t, sv, r, (unsigned long long *)sv.bid.p);
+    bool solved = false;
+    int64_t known_range = -1;
+    for (int bpc : {1, 2, 4}) {
+        bool fits = false;
+        if (known_range > 65534 && bpc == 2) continue;  // u16 cannot hold it either
+        // u8 is tried speculatively (no host round trip in the common case)
+        const bool spec = (bpc == 1) && g_speculate;
+        if ((rc = sv_compress(sv, bpc, &fits, spec))) return rc;
+        if (!fits) continue;
+        TD_DISPATCH(sv, sv_begin_t, sv);
         if (rc) return rc;
-        TD_DISPATCH(sv, sv_apply_t, sv, r, (unsigned long long *)sv.bid.p);
+        for (int r = 0; r < max_rounds; r++) {
+            TD_DISPATCH(sv, sv_bid_t, sv, r, (unsigned long long *)sv.bid.p);
+            if (rc) return rc;
+            TD_DISPATCH(sv, sv_apply_t, sv, r, (unsigned long long *)sv.bid.p);
+            if (rc) return rc;
+        }
+        ShardTab tab{};
+        tab.p[0] = sv.cc.p;
+        tab.rps = n;
+        tab.count = 1;
+        TD_DISPATCH(sv, sv_finish_t, sv, tab, (int *)sv.r2c.p);
         if (rc) return rc;
+        TD_DISPATCH(sv, sv_totals_t, sv, dual_bound != nullptr);
+        if (rc) return rc;
+        int flag = 0;
+        if ((rc = sv_readback(sv, &tot, &dual, max_rounds, spec ? &flag : nullptr))) return rc;
+        if (spec && flag) {  // rows did not fit u8: redo with the width the recorded range needs
+            known_range = c.stats[6];
+            continue;
+        }
+        solved = true;
+        break;
     }
-    ShardTab tab{};
-    tab.p[0] = sv.cc.p;
-    tab.rps = n;
-    tab.count = 1;
-    TD_DISPATCH(sv, sv_finish_t, sv, tab, (int *)sv.r2c.p);
-    if (rc) return rc;
-    TD_DISPATCH(sv, sv_totals_t, sv, dual_bound != nullptr);
-    if (rc) return rc;
-    if ((rc = sv_readback(sv, &tot, &dual, max_rounds))) return rc;
+    if (!solved) return fail(TD_ERANGE, "row cost range exceeds 2^32-2");
     if (is_device_ptr(row_to_col)) {
         TD_HIP(hipMemcpyAsync(row_to_col, sv.r2c.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c.stream));
     } else {

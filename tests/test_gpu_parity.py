@@ -336,3 +336,30 @@ def test_randomized_differential(td):
         assert total == ref == dual, (it, n, mode, total, ref, dual)
         assert sorted(r2c.tolist()) == list(range(n))
         assert int(c[np.arange(n), r2c].astype(np.int64).sum()) == total
+
+
+@pytest.mark.parametrize("n,width", [(20000, 1), (9000, 2), (5000, 4), (33000, 1)])
+def test_assign_multi_chunk_finisher_paths(td, n, width):
+    """Sizes where a finisher thread owns several 16-byte chunks (u8 > 16384, u16 > 8192,
+    u32 > 4096 columns).  perf.jl-like instance (optimum 10*n known from the row-minimum bound),
+    widened to u16 / u32 storage by one expensive column per row."""
+    import torch
+    from taxidispatcher_amd import _ffi
+    cost = torch.empty((n, n), dtype=torch.int32, device="cuda")
+    _ffi.check(_ffi.lib().td_gen_uniform(n, 5, 10, 40, 0, n, cost.data_ptr()))
+    if width == 2:
+        cost[:, 0] = 5000          # row range > 254 -> u16 storage
+    elif width == 4:
+        cost[:, 0] = 250000        # big_cost sentinel -> u32 storage
+    r2c, total, dual = td.assign(cost, n, want_dual=True)
+    assert td.last_stats()["bytes_per_cell"] == width
+    assert total == dual
+    assert sorted(r2c.tolist()) == list(range(n))
+    picked = cost[torch.arange(n, device="cuda"), torch.from_numpy(r2c.astype(np.int64)).cuda()]
+    assert int(picked.sum().item()) == total
+    if width == 1:
+        assert total == 10 * n
+    else:   # column 0 must be taken by exactly one row; everything else at its row minimum
+        assert total == 10 * (n - 1) + (5000 if width == 2 else 250000)
+    del cost
+    torch.cuda.empty_cache()
