@@ -85,7 +85,7 @@ enum {
 constexpr int ROW_BITS = 20;
 
 // tunables (env TD_MAX_ROUNDS / TD_TIE_EVICT / TD_LDS_ROUNDS, read once at td_assign)
-int g_max_rounds = 12, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1, g_row_rounds = 2, g_cgrid = 6, g_creg = 1, g_psap_batches = 16, g_psap_min = 12, g_psap_u8 = 0, g_speculate = 1;
+int g_max_rounds = 12, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1, g_row_rounds = 2, g_cgrid = 6, g_creg = 1, g_psap_batches = 16, g_psap_min = 12, g_psap_u8 = 0, g_speculate = 1, g_psap8_batches = 1, g_psap8_grid = 64;
 void read_tunables()
 {
     static bool done = false;
@@ -102,6 +102,8 @@ void read_tunables()
     if (const char *e = getenv("TD_PSAP_MIN")) g_psap_min = std::max(1, atoi(e));
     if (const char *e = getenv("TD_PSAP_U8")) g_psap_u8 = atoi(e) != 0;
     if (const char *e = getenv("TD_SPECULATE")) g_speculate = atoi(e) != 0;
+    if (const char *e = getenv("TD_PSAP8")) g_psap8_batches = std::max(0, std::min(32, atoi(e)));
+    if (const char *e = getenv("TD_PSAP8_GRID")) g_psap8_grid = std::max(1, std::min(192, atoi(e)));
 }
 
 // ---- unpack one 16-byte chunk into E cost values -----------------------------------
@@ -586,6 +588,44 @@ __global__ __launch_bounds__(256) void k_assign(int n, int nrows, int row0, unsi
     }
 }
 
+// Ordered list of the free rows (r2c < 0), built by ONE workgroup: every thread counts the free
+// rows of its own contiguous slice, one block-wide exclusive scan (wave DPP-free shuffle scan +
+// 16-entry LDS exchange), then every thread writes its rows at its offset.  Returns the count.
+__device__ __forceinline__ int build_free_list(int n, const int *__restrict__ r2c, int *__restrict__ list)
+{
+    __shared__ int s_fl_w[16];
+    __shared__ int s_fl_tot;
+    const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
+    const int per = (n + T - 1) / T;
+    const int lo = tid * per, hi = min(n, lo + per);
+    int cnt = 0;
+    for (int r = lo; r < hi; r++) cnt += (r2c[r] < 0) ? 1 : 0;
+    int incl = cnt;  // inclusive scan within the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_fl_w[w] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < w; k++) base += s_fl_w[k];
+    if (tid == T - 1) s_fl_tot = base + incl;
+    int pos = base + incl - cnt;
+    for (int r = lo; r < hi; r++)
+        if (r2c[r] < 0) list[pos++] = r;
+    __syncthreads();
+    return s_fl_tot;
+}
+
+__global__ __launch_bounds__(1024) void k_freelist(int n, const int *__restrict__ r2c, int *__restrict__ list,
+                                                   int *__restrict__ ctl)
+{
+    if (ctl[CTL_FLAG]) return;
+    const int cnt = build_free_list(n, r2c, list);
+    if (threadIdx.x == 0) ctl[CTL_NFREE] = cnt;
+}
+
 // =====================================================================================
 // k_sap: shortest augmenting paths, one persistent workgroup
 // =====================================================================================
@@ -693,27 +733,8 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab
         P[j] = pk[j] >> 1;
         if (LDSST) OWN[j] = owner_g[j];
     }
-    // ordered list of free rows (deterministic augmentation order)
-    if (tid == 0) s_nfree = 0;
-    __syncthreads();
-    for (int r0 = 0; r0 < n; r0 += T) {
-        const int r = r0 + tid;
-        const bool fr = r < n && r2c[r] < 0;
-        const unsigned long long m = __ballot(fr);
-        if (lane == 0) s_wcnt[w] = __popcll(m);
-        __syncthreads();
-        int base = s_nfree;
-        for (int k = 0; k < w; k++) base += s_wcnt[k];
-        if (fr) list[base + __popcll(m & ((1ull << lane) - 1ull))] = r;
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int k = 0; k < nw; k++) tot += s_wcnt[k];
-            s_nfree += tot;
-        }
-        __syncthreads();
-    }
-    const int nfree = s_nfree;
+    // the ordered list of free rows was built by k_freelist / the last k_pcommit
+    const int nfree = ctl[CTL_NFREE];
     __syncthreads();
 
     // columns owned by this thread: chunk q*T + tid, q = 0..CH-1
@@ -912,11 +933,27 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab
 constexpr int SAP_W = 16;  // columns of one tie class finalised per step
 constexpr int SAP_G = 4;   // rows streamed per load group
 
-template <bool LDSST>
+constexpr int PS_G = 192;     // searches per batch
+constexpr int PS_CAP = 4096;  // finalised columns recorded per search; longer searches are left to the serial finisher
+
+template <typename PT>
+struct PsRec {
+    int f, endcol, nS, plen, status;  // status 1 = usable
+    int pad[3];
+    PT mind;
+    int S_col[PS_CAP];
+    PT S_d[PS_CAP];
+    int path[PS_CAP + 2];
+};
+
+// SPEC = false: the serial finisher (applies every augmentation itself).
+// SPEC = true : one speculative search per workgroup against a read-only snapshot; the search is
+//               recorded in recs[blockIdx.x] and applied (or rejected) by k_pcommit.
+template <bool LDSST, bool SPEC>
 __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTab tab, int32_t *__restrict__ pk,
                                                int *__restrict__ owner_g, int *__restrict__ r2c,
                                                int *__restrict__ pred_g, int *__restrict__ list,
-                                               int *__restrict__ ctl)
+                                               int *__restrict__ ctl, PsRec<int32_t> *__restrict__ recs)
 {
     constexpr int E = 16;
     constexpr uint32_t AMAX = 0x7FFFFFFFu;
@@ -929,39 +966,25 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
     __shared__ int s_rj[2][16];
     __shared__ int s_wcnt[16];
     __shared__ int s_nfree;
+    __shared__ int s_end[2];
 
     if (ctl[CTL_FLAG]) return;
+    if (SPEC && (int)blockIdx.x >= ctl[CTL_NFREE]) return;
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
     const int npad = nchunks * E;
     const size_t pitch = (size_t)npad;
-    int32_t *P = pk;
     int *OWN = LDSST ? reinterpret_cast<int *>(smem) : owner_g;
     int *PRED = LDSST ? reinterpret_cast<int *>(smem + (size_t)npad * sizeof(int)) : pred_g;
 
-    for (int j = tid; j < npad; j += T) {
-        P[j] = pk[j] >> 1;
-        if (LDSST) OWN[j] = owner_g[j];
+    // free rows: ordered list built by k_freelist / the last k_pcommit
+    const int nfree = SPEC ? 1 : ctl[CTL_NFREE];
+    if (!SPEC && nfree == 0) {
+        if (tid == 0) ctl[CTL_STEPS] = 0;
+        return;
     }
-    if (tid == 0) s_nfree = 0;
-    __syncthreads();
-    for (int r0 = 0; r0 < n; r0 += T) {
-        const int r = r0 + tid;
-        const bool fr = r < n && r2c[r] < 0;
-        const unsigned long long m = __ballot(fr);
-        if (lane == 0) s_wcnt[w] = __popcll(m);
-        __syncthreads();
-        int base = s_nfree;
-        for (int k = 0; k < w; k++) base += s_wcnt[k];
-        if (fr) list[base + __popcll(m & ((1ull << lane) - 1ull))] = r;
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int k = 0; k < nw; k++) tot += s_wcnt[k];
-            s_nfree += tot;
-        }
-        __syncthreads();
-    }
-    const int nfree = s_nfree;
+    if (LDSST)
+        for (int j = tid; j < npad; j += T) OWN[j] = owner_g[j];
+    if (tid == 0) s_end[0] = s_end[1] = INT_MAX;
     __syncthreads();
 
     const bool has = tid < nchunks;
@@ -969,8 +992,19 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
     long long steps = 0;
     int par = 0;
     bool bad = false;
+    PsRec<int32_t> *rec = SPEC ? recs + blockIdx.x : nullptr;
     for (int fi = 0; fi < nfree && !bad; fi++) {
-        const int f = list[fi];
+        int f, rott = 0;
+        if (SPEC) {
+            // searches of a batch are spread evenly over the (row-ordered) free list, and ties
+            // between free end columns are broken in a thread order rotated per search
+            const int nf = ctl[CTL_NFREE];
+            const int gact = nf < (int)gridDim.x ? nf : (int)gridDim.x;
+            f = list[(int)(((long long)blockIdx.x * nf) / gact)];
+            rott = (int)(((uint64_t)(((uint32_t)f + 1u) * 0x9E3779B1u) * (uint64_t)T) >> 32);
+        } else {
+            f = list[fi];
+        }
         // key[e] = (dist+1) << 5 | owned << 4 | e ; a finalised or non-existent column keeps only
         // its low 5 bits: it can never be improved (any candidate key is >= it) and, seen through
         // "key - 32" (unsigned wrap), never wins the argmin.
@@ -987,10 +1021,10 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
             for (int e = 0; e < E; e++) {
                 const int j = jbase + e;
                 const bool valid = has && j < n;
-                const int32_t p = valid ? P[j] : 0;
+                const int32_t p = valid ? (pk[j] >> 1) : 0;
                 const int o = valid ? OWN[j] : -2;
                 preg[e] = p;
-                predr[e] = f;
+                predr[e] = SPEC ? -1 : f;
                 const uint32_t low = ((o != -1) ? 16u : 0u) | (uint32_t)e;
                 key[e] = valid ? (((c[e] + (uint32_t)p + 1u) << 5) | low) : low;
             }
@@ -1038,17 +1072,29 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
             const int32_t bd = (int32_t)(mg >> 5);
             const bool mine_d = (m >> 5) == (uint32_t)bd;  // this lane holds a column at the frontier distance
             if (!(mg & 16u)) {  // a FREE column is at the frontier distance: the search ends there
-                // its index: the lane holding the global minimum key publishes it
-                if (m == mg) s_bj[par][0] = jbase + (int)(m & 15u);
+                // several threads can hold a column with this key: the first in (rotated) thread
+                // order wins — deterministic, and different for different speculative searches
+                if (m == mg) {
+                    int rt = tid - rott;
+                    rt += (rt < 0) ? T : 0;
+                    atomicMin(&s_end[par], rt);
+                }
                 __syncthreads();
-                endcol = s_bj[par][0];
+                int wt = s_end[par] + rott;
+                wt -= (wt >= T) ? T : 0;
+                endcol = wt * E + (int)(mg & 15u);
                 mind = bd;
+                if (tid == 0) s_end[par ^ 1] = INT_MAX;
                 par ^= 1;
                 break;
             }
             // every column at the frontier distance is owned: finalise up to SAP_W of them in this
             // step (ordered by thread) — one memory round trip serves the whole tie class
             const int nb = total < SAP_W ? total : SAP_W;
+            if (SPEC && steps + nb > PS_CAP) {  // too long for a speculative record
+                bad = true;
+                break;
+            }
             const unsigned long long myb = __ballot(mine_d);
             const int rank = base + __popcll(myb & ((1ull << lane) - 1ull));
             const bool sel = mine_d && rank < SAP_W;
@@ -1059,6 +1105,10 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
                 if (sel) {
                     s_bj[par][rank] = jbase + (int)(m & 15u);
                     s_bp[par][rank] = pe;
+                    if (SPEC) {
+                        rec->S_col[steps + rank] = jbase + (int)(m & 15u);
+                        rec->S_d[steps + rank] = bd;
+                    }
                 }
                 // finalise my column: pending dual change goes into preg, key keeps only its low bits
 #pragma unroll
@@ -1069,6 +1119,7 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
                 }
                 sc |= sel ? (1u << (m & 15u)) : 0u;
             }
+            if (tid == 0) s_end[par ^ 1] = INT_MAX;
             __syncthreads();
             steps += nb;
             // stream the owners' rows of the batch in groups of SAP_G (that many 16-byte loads in
@@ -1087,7 +1138,7 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
                     const int bj = __builtin_amdgcn_readfirstlane(s_bj[lpar][qq]);
                     const int bp = __builtin_amdgcn_readfirstlane(s_bp[lpar][qq]);
                     const int o = __builtin_amdgcn_readfirstlane(OWN[bj]);
-                    ob[q] = o;
+                    ob[q] = SPEC ? bj : o;   // predecessor: column (speculative record) or row
                     const uint8_t *rp = shard_row<uint8_t>(tab, o, pitch);
                     cs[q] = (int)rp[bj];       // consumed after ALL loads of the group are issued
                     t1[q] = bd - bp + 1;       // dist - row dual of o (+1: key bias), minus cs[q] below
@@ -1117,32 +1168,56 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
         }
         if (has) {
             // dual update of finalised columns (their -dist is already folded into preg) + pred flush
+            if (!SPEC) {
 #pragma unroll
-            for (int e = 0; e < E; e++)
-                if ((sc >> e) & 1u) P[jbase + e] = preg[e] + mind;
+                for (int e = 0; e < E; e++)
+                    if ((sc >> e) & 1u) pk[jbase + e] = ((preg[e] + mind) << 1) | 1;
+            }
 #pragma unroll
             for (int e = 0; e < E; e += 4)
                 *reinterpret_cast<int4 *>(&PRED[jbase + e]) = make_int4(predr[e], predr[e + 1], predr[e + 2], predr[e + 3]);
         }
         __syncthreads();
-        if (tid == 0) {  // flip the path
-            int j = endcol;
-            for (int hop = 0; hop <= n; hop++) {
-                const int i = PRED[j];
-                OWN[j] = i;
-                const int jn = r2c[i];
-                r2c[i] = j;
-                j = jn;
-                if (i == f) break;
+        if (tid == 0) {
+            if (SPEC) {  // record the path as columns: end column first, predecessors after
+                int plen = 0, j = endcol;
+                while (j >= 0 && plen <= PS_CAP) {
+                    rec->path[plen++] = j;
+                    j = PRED[j];
+                }
+                rec->plen = plen;
+                if (j >= 0) bad = true;
+            } else {  // flip the path
+                int j = endcol;
+                for (int hop = 0; hop <= n; hop++) {
+                    const int i = PRED[j];
+                    OWN[j] = i;
+                    if (LDSST) owner_g[j] = i;   // write-through: no epilogue copy
+                    if (j == endcol) pk[j] = pk[j] | 1;
+                    const int jn = r2c[i];
+                    r2c[i] = j;
+                    j = jn;
+                    if (i == f) break;
+                }
             }
         }
         __syncthreads();
+        if (SPEC) {
+            if (tid == 0) {
+                rec->f = f;
+                rec->endcol = endcol;
+                rec->nS = (int)steps;
+                rec->mind = mind;
+                rec->status = bad ? 0 : 1;
+            }
+            return;
+        }
+    }
+    if (SPEC) {  // search aborted (record too long / no candidate): the row stays free
+        if (tid == 0) recs[blockIdx.x].status = 0;
+        return;
     }
     __syncthreads();
-    for (int j = tid; j < npad; j += T) {
-        pk[j] = (int32_t)(P[j] << 1) | 1;
-        if (LDSST && j < n) owner_g[j] = OWN[j];
-    }
     if (tid == 0) {
         ctl[CTL_NFREE] = nfree;
         ctl[CTL_STEPS] = (int)(steps > INT_MAX ? INT_MAX : steps);
@@ -1168,19 +1243,6 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
 // Results do not depend on workgroup timing: searches of a batch share one snapshot and the
 // claim is a min over ids.
 // =====================================================================================
-constexpr int PS_G = 192;     // searches per batch
-constexpr int PS_CAP = 4096;  // finalised columns recorded per search; longer searches are left to the serial finisher
-
-template <typename PT>
-struct PsRec {
-    int f, endcol, nS, plen, status;  // status 1 = usable
-    int pad[3];
-    PT mind;
-    int S_col[PS_CAP];
-    PT S_d[PS_CAP];
-    int path[PS_CAP + 2];
-};
-
 template <typename CT, bool LDSST>
 __global__ __launch_bounds__(1024) void k_psearch(int n, int nchunks, const ShardTab tab,
                                                   const typename Tr<CT>::PT *__restrict__ pk,
@@ -1355,7 +1417,7 @@ template <typename PT>
 __global__ __launch_bounds__(1024) void k_pcommit(int n, PT *__restrict__ pk, int *__restrict__ owner, int *__restrict__ r2c,
                                                   int *__restrict__ list, int *__restrict__ ctl,
                                                   unsigned long long *__restrict__ raise,  // n words, all zero on entry/exit
-                                                  const PsRec<PT> *__restrict__ recs, int first)
+                                                  const PsRec<PT> *__restrict__ recs, int first, int ngrid = PS_G)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     int *touch = reinterpret_cast<int *>(smem);  // n ints
@@ -1364,7 +1426,7 @@ __global__ __launch_bounds__(1024) void k_pcommit(int n, PT *__restrict__ pk, in
     __shared__ int s_nfree;
     __shared__ int s_acc;
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
-    const int nres = first ? 0 : min(ctl[CTL_NFREE], PS_G);
+    const int nres = first ? 0 : min(ctl[CTL_NFREE], ngrid);
     if (!first && nres == 0) return;
     for (int j = tid; j < n; j += T) {
         touch[j] = INT_MAX;
@@ -1411,36 +1473,27 @@ __global__ __launch_bounds__(1024) void k_pcommit(int n, PT *__restrict__ pk, in
     }
     __threadfence();
     __syncthreads();
-    // phase 2b: apply the raises (max over the accepted searches) and refresh the owned bits
-    for (int j = tid; j < n; j += T) {
-        const unsigned long long rv = __hip_atomic_load(&raise[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        PT p = pk[j] >> 1;
-        if (rv) {
-            p += (PT)rv;
-            raise[j] = 0ull;
+    // phase 2b: apply the raises — max over the accepted searches, each column exactly once (the
+    // first search to swap the slot to zero applies it); only touched columns are visited
+    for (int r = w; r < nres; r += nw) {
+        const PsRec<PT> *rc = recs + r;
+        if (rc->status != 1) continue;
+        bool ok = true;
+        for (int k = lane; k < rc->plen; k += 64) ok = ok && (touch[rc->path[k]] == r);
+        for (int k = lane; k < rc->nS; k += 64) ok = ok && (pthm[rc->S_col[k]] >= r);
+        if (__ballot(!ok)) continue;
+        for (int k = lane; k < rc->nS; k += 64) {
+            const int col = rc->S_col[k];
+            const unsigned long long rv = atomicExch(&raise[col], 0ull);
+            if (rv) pk[col] = pk[col] + (PT)((PT)rv << 1);
         }
-        pk[j] = (PT)(p << 1) | (PT)(owner[j] >= 0 ? 1 : 0);
+        if (lane == 0) pk[rc->endcol] = pk[rc->endcol] | (PT)1;  // the end column has an owner now
     }
-    // phase 3: ordered list of the rows that are still free
-    if (tid == 0) s_nfree = 0;
     __syncthreads();
-    for (int r0 = 0; r0 < n; r0 += T) {
-        const int r = r0 + tid;
-        const bool fr = r < n && r2c[r] < 0;
-        const unsigned long long m = __ballot(fr);
-        if (lane == 0) s_wcnt[w] = __popcll(m);
-        __syncthreads();
-        int base = s_nfree;
-        for (int k = 0; k < w; k++) base += s_wcnt[k];
-        if (fr) list[base + __popcll(m & ((1ull << lane) - 1ull))] = r;
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int k = 0; k < nw; k++) tot += s_wcnt[k];
-            s_nfree += tot;
-        }
-        __syncthreads();
-    }
+    // phase 3: ordered list of the rows that are still free
+    const int nleft = build_free_list(n, r2c, list);
+    if (tid == 0) s_nfree = nleft;
+    __syncthreads();
     if (tid == 0) {
         // nothing accepted (every search overflowed): stop launching useful work for later batches
         ctl[CTL_NFREE] = (!first && s_acc == 0) ? 0 : s_nfree;
@@ -1740,6 +1793,7 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
     const size_t shm = lds ? st : 0;
     if (CH * E > 64) return fail(TD_ERANGE, "n=%d too large for the single-workgroup finisher", n);
     ProfScope ps(TD_K_SAP);
+    k_freelist<<<1, 1024, 0, ctx().stream>>>(n, r2c_full, (int *)sv.list.p, (int *)sv.misc.p);
     // ---- speculative parallel searches first (a few batches), the serial workgroup mops up
     // (u8 instances go straight to the lean tie-batching serial workgroup, which is faster there)
     if (g_psap_batches > 0 && CH == 1 && lds && n >= 64 && (sizeof(CT) > 1 || g_psap_u8)) {
@@ -1754,8 +1808,6 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
         if (cshm > 48 * 1024)
             (void)hipFuncSetAttribute((const void *)k_pcommit<PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cshm);
         unsigned long long *raise = (unsigned long long *)sv.bid.p;  // all zero after the bidding rounds
-        k_pcommit<PT><<<1, 1024, cshm, c.stream>>>(n, (PT *)sv.price.p, (int *)sv.owner.p, r2c_full, (int *)sv.list.p,
-                                                   (int *)sv.misc.p, raise, recs, 1);
         // one small read-back decides how many speculative batches are worth launching: with a
         // handful of free rows the serial (tie-batching) workgroup is faster than any batch
         TD_HIP(hipMemcpyAsync(c.pinned, (int *)sv.misc.p + CTL_NFREE, sizeof(int), hipMemcpyDeviceToHost, c.stream));
@@ -1774,14 +1826,35 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
     if constexpr (sizeof(CT) == 1) {
         if (CH == 1 && g_sap8) {
             Ctx &c = ctx();
+            if (lds && g_psap8_batches > 0 && n >= 64) {
+                // u8: the free rows (a handful on perf.jl instances) are searched concurrently by
+                // the lean tie-batching search, one workgroup each; no host read-back — workgroups
+                // beyond the number of free rows exit at once
+                int rc = ensure(sv.psrec, sizeof(PsRec<int32_t>) * (size_t)PS_G);
+                if (rc) return rc;
+                PsRec<int32_t> *recs = (PsRec<int32_t> *)sv.psrec.p;
+                const size_t cshm = 2 * sizeof(int) * (size_t)n;
+                if (shm > 48 * 1024)
+                    (void)hipFuncSetAttribute((const void *)k_sap8<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                if (cshm > 48 * 1024)
+                    (void)hipFuncSetAttribute((const void *)k_pcommit<int32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cshm);
+                unsigned long long *raise = (unsigned long long *)sv.bid.p;
+                for (int b = 0; b < g_psap8_batches; b++) {
+                    k_sap8<true, true><<<g_psap8_grid, T, shm, c.stream>>>(n, nchunks, tab, (int32_t *)sv.price.p, (int *)sv.owner.p,
+                                                                          r2c_full, (int *)sv.pred.p, (int *)sv.list.p,
+                                                                          (int *)sv.misc.p, recs);
+                    k_pcommit<int32_t><<<1, 1024, cshm, c.stream>>>(n, (int32_t *)sv.price.p, (int *)sv.owner.p, r2c_full,
+                                                                    (int *)sv.list.p, (int *)sv.misc.p, raise, recs, 0, g_psap8_grid);
+                }
+            }
             if (lds) {
                 if (shm > 48 * 1024)
-                    (void)hipFuncSetAttribute((const void *)k_sap8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-                k_sap8<true><<<1, T, shm, c.stream>>>(sv.n, sv.nchunks, tab, (int32_t *)sv.price.p, (int *)sv.owner.p, r2c_full,
-                                                      (int *)sv.pred.p, (int *)sv.list.p, (int *)sv.misc.p);
+                    (void)hipFuncSetAttribute((const void *)k_sap8<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                k_sap8<true, false><<<1, T, shm, c.stream>>>(sv.n, sv.nchunks, tab, (int32_t *)sv.price.p, (int *)sv.owner.p, r2c_full,
+                                                             (int *)sv.pred.p, (int *)sv.list.p, (int *)sv.misc.p, nullptr);
             } else {
-                k_sap8<false><<<1, T, 0, c.stream>>>(sv.n, sv.nchunks, tab, (int32_t *)sv.price.p, (int *)sv.owner.p, r2c_full,
-                                                     (int *)sv.pred.p, (int *)sv.list.p, (int *)sv.misc.p);
+                k_sap8<false, false><<<1, T, 0, c.stream>>>(sv.n, sv.nchunks, tab, (int32_t *)sv.price.p, (int *)sv.owner.p, r2c_full,
+                                                            (int *)sv.pred.p, (int *)sv.list.p, (int *)sv.misc.p, nullptr);
             }
             TD_HIP(hipGetLastError());
             return TD_OK;
