@@ -85,7 +85,7 @@ enum {
 constexpr int ROW_BITS = 20;
 
 // tunables (env TD_MAX_ROUNDS / TD_TIE_EVICT / TD_LDS_ROUNDS, read once at td_assign)
-int g_max_rounds = 12, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1, g_row_rounds = 2, g_cgrid = 6, g_creg = 1, g_psap_batches = 16, g_psap_min = 12, g_psap_u8 = 0, g_speculate = 1, g_psap8_batches = 1, g_psap8_grid = 64;
+int g_max_rounds = 12, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1, g_row_rounds = 2, g_cgrid = 6, g_creg = 1, g_psap_batches = 16, g_psap_min = 12, g_psap_u8 = 0, g_speculate = 1, g_psap8_batches = 1, g_psap8_grid = 64, g_fuse_bid0 = 0;  // fused round 0: measured slower (0.431 vs 0.268+0.085 ms)
 void read_tunables()
 {
     static bool done = false;
@@ -102,6 +102,7 @@ void read_tunables()
     if (const char *e = getenv("TD_PSAP_MIN")) g_psap_min = std::max(1, atoi(e));
     if (const char *e = getenv("TD_PSAP_U8")) g_psap_u8 = atoi(e) != 0;
     if (const char *e = getenv("TD_SPECULATE")) g_speculate = atoi(e) != 0;
+    if (const char *e = getenv("TD_FUSE_BID0")) g_fuse_bid0 = atoi(e) != 0;
     if (const char *e = getenv("TD_PSAP8")) g_psap8_batches = std::max(0, std::min(32, atoi(e)));
     if (const char *e = getenv("TD_PSAP8_GRID")) g_psap8_grid = std::max(1, std::min(192, atoi(e)));
 }
@@ -239,14 +240,21 @@ __global__ __launch_bounds__(256) void k_compress(int n, int nrows, int nchunks,
 // Register-resident variant: the row is read ONCE from HBM (all VPT 16-byte loads of a thread
 // are issued back to back, so a 256-thread workgroup keeps 64 KiB in flight), reduced, and
 // written back narrow.  Needs n % 4 == 0, a 16-byte aligned matrix and n/4 <= THREADS*VPT.
-template <typename CT, int VPT, int THREADS>
+// BID0: also performs bidding round 0 for the row while it is in registers (prices are all zero and
+// every column is free in round 0, so the bid needs nothing but the row): saves the first 1-byte
+// pass over the narrow copy and one launch.  Same rotation hash and tie-break as k_bid, so the
+// fused and the separate round 0 publish identical keys.
+template <typename CT, int VPT, int THREADS, bool BID0 = false>
 __global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nrows, int nchunks, const int32_t *__restrict__ cost,
                                                           CT *__restrict__ cc, int32_t *__restrict__ rowmin,
-                                                          int *__restrict__ ctl)
+                                                          int *__restrict__ ctl, unsigned long long *__restrict__ bid = nullptr,
+                                                          int row0 = 0)
 {
     constexpr int E = Tr<CT>::E;
     constexpr int NW = THREADS / 64;
     __shared__ int s_mn[2][NW], s_mx[2][NW];
+    __shared__ long long s_bk[2][NW], s_bx[2][NW];
+    __shared__ int s_bpz[2][NW];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const size_t pitch = (size_t)nchunks * E;
     const int nq = n >> 2;
@@ -309,6 +317,77 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nrows, int 
         }
         // sentinel tail up to the 16-byte chunk boundary
         for (int j = n + tid; j < (int)pitch; j += THREADS) dst[j] = (CT)Tr<CT>::SENT;
+        if constexpr (BID0) {
+            using PT = typename Tr<CT>::PT;
+            const int grow = row0 + row;
+            const uint32_t hsh = ((uint32_t)grow + 1u) * 0x9E3779B1u;  // round 0
+            const int rot = (int)(((uint64_t)(hsh ^ (hsh >> 15)) * (uint64_t)nchunks) >> 32);
+            PT k1 = Tr<CT>::KMAX, k2 = Tr<CT>::KMAX;
+            int pos1 = INT_MAX;
+#pragma unroll
+            for (int k = 0; k < VPT; k++) {
+                const int q = k * THREADS + tid;
+                if (q < nq) {
+                    const int col0 = q << 2;
+                    int t = (col0 / E) - rot;
+                    t += (t < 0) ? nchunks : 0;
+                    const int pb = t * E + (col0 % E);
+                    const int vv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const PT key = (PT)2 * (PT)(uint32_t)(vv[e] - mn);
+                        const int pos = pb + e;
+                        const bool lt = (key < k1) || (key == k1 && pos < pos1);
+                        const PT loser = lt ? k1 : key;
+                        k2 = k2 < loser ? k2 : loser;
+                        k1 = lt ? key : k1;
+                        pos1 = lt ? pos : pos1;
+                    }
+                }
+            }
+            PT bk = k1;
+            int bp = pos1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const PT ok = shfl_xor_t(bk, o);
+                const int op = __shfl_xor(bp, o);
+                if (ok < bk || (ok == bk && op < bp)) {
+                    bk = ok;
+                    bp = op;
+                }
+            }
+            const bool winner = (k1 == bk) && (bp == pos1) && (pos1 != INT_MAX);
+            PT x = winner ? k2 : k1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const PT ox = shfl_xor_t(x, o);
+                x = ox < x ? ox : x;
+            }
+            if (lane == 0) {
+                s_bk[par][w] = (long long)bk;
+                s_bpz[par][w] = bp;
+                s_bx[par][w] = (long long)x;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int wb = 0;
+                for (int k = 1; k < NW; k++)
+                    if (s_bk[par][k] < s_bk[par][wb] || (s_bk[par][k] == s_bk[par][wb] && s_bpz[par][k] < s_bpz[par][wb])) wb = k;
+                const long long gk = s_bk[par][wb];
+                const int gp = s_bpz[par][wb];
+                long long gx = s_bx[par][wb];
+                for (int k = 0; k < NW; k++)
+                    if (k != wb && s_bk[par][k] < gx) gx = s_bk[par][k];
+                if (gp != INT_MAX) {
+                    const int t1 = gp / E;
+                    int ch = t1 + rot;
+                    if (ch >= nchunks) ch -= nchunks;
+                    const int j1 = ch * E + (gp - t1 * E);
+                    const long long inc = (gx == (long long)Tr<CT>::KMAX) ? 0 : ((gx >> 1) - (gk >> 1));
+                    if (j1 < n) atomicMax(&bid[j1], ((unsigned long long)inc << ROW_BITS) | (unsigned long long)(grow + 1));
+                }
+            }
+        }
     }
 }
 
@@ -1608,6 +1687,7 @@ __global__ __launch_bounds__(256) void k_dual(int n, int nrows, int row0, int nc
 struct td_shard {
     int n = 0, row0 = 0, nrows = 0;
     int bpc = 0;  // bytes per stored cell: 1, 2, 4 (0 = not compressed yet)
+    bool fused_bid0 = false;  // the compress pass already published bidding round 0
     int nchunks = 0, npad = 0;
     const int32_t *d_cost = nullptr;  // nrows x n, device
     Buf stage, cc, price, owner, r2c, r2c_full, bid, pred, list, rowmin, misc, psrec;
@@ -1652,7 +1732,7 @@ int sv_prepare(Solver &sv, int n, int row0, int nrows, const int32_t *cost)
 }
 
 template <typename CT>
-int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
+int sv_compress_t(Solver &sv, bool *fits, bool speculate = false, bool bid0 = false)
 {
     Ctx &c = ctx();
     constexpr int E = Tr<CT>::E;
@@ -1664,6 +1744,7 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
     TD_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(int), c.stream));  // flag, error, stats, range
     const bool vec = (n % 4 == 0) && (((uintptr_t)sv.d_cost & 15) == 0);
     const int grid = std::max(1, std::min(nrows, c.n_cu * 8));
+    sv.fused_bid0 = false;
     if (nrows > 0) {
         ProfScope ps(TD_K_COMPRESS);
         const int nq = n / 4;
@@ -1671,13 +1752,19 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
         int32_t *rm = (int32_t *)sv.rowmin.p;
         if (g_creg && vec && nq <= 256 * 16) {
             const int g2 = std::max(1, std::min(nrows, c.n_cu * g_cgrid));
-#define TD_CR(VPT) k_compress_reg<CT, VPT, 256><<<g2, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl)
-            if (nq <= 256) TD_CR(1);
-            else if (nq <= 512) TD_CR(2);
-            else if (nq <= 1024) TD_CR(4);
-            else if (nq <= 2048) TD_CR(8);
-            else TD_CR(16);
+#define TD_CR(VPT)                                                                                                          \
+    if (bid0)                                                                                                          \
+        k_compress_reg<CT, VPT, 256, true><<<g2, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl,       \
+                                                                    (unsigned long long *)sv.bid.p, sv.row0);          \
+    else                                                                                                               \
+        k_compress_reg<CT, VPT, 256><<<g2, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl)
+            if (nq <= 256) { TD_CR(1); }
+            else if (nq <= 512) { TD_CR(2); }
+            else if (nq <= 1024) { TD_CR(4); }
+            else if (nq <= 2048) { TD_CR(8); }
+            else { TD_CR(16); }
 #undef TD_CR
+            sv.fused_bid0 = bid0;
         } else if (g_creg && vec && nq <= 1024 * 16) {
             k_compress_reg<CT, 16, 1024><<<std::max(1, std::min(nrows, c.n_cu * 2)), 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl);
         } else if (vec)
@@ -1703,10 +1790,10 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
     return TD_OK;
 }
 
-int sv_compress(Solver &sv, int bpc, bool *fits, bool speculate = false)
+int sv_compress(Solver &sv, int bpc, bool *fits, bool speculate = false, bool bid0 = false)
 {
     switch (bpc) {
-        case 1: return sv_compress_t<uint8_t>(sv, fits, speculate);
+        case 1: return sv_compress_t<uint8_t>(sv, fits, speculate, bid0);
         case 2: return sv_compress_t<uint16_t>(sv, fits, speculate);
         case 4: return sv_compress_t<uint32_t>(sv, fits, speculate);
     }
@@ -1987,13 +2074,26 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         if (known_range > 65534 && bpc == 2) continue;  // u16 cannot hold it either
         // u8 is tried speculatively (no host round trip in the common case)
         const bool spec = (bpc == 1) && g_speculate;
-        if ((rc = sv_compress(sv, bpc, &fits, spec))) return rc;
-        if (!fits) continue;
-        TD_DISPATCH(sv, sv_begin_t, sv);
-        if (rc) return rc;
-        for (int r = 0; r < max_rounds; r++) {
-            TD_DISPATCH(sv, sv_bid_t, sv, r, (unsigned long long *)sv.bid.p);
+        const bool fuse0 = spec && g_fuse_bid0 && g_creg && (n % 4 == 0) && n / 4 <= 256 * 16 && (((uintptr_t)sv.d_cost & 15) == 0);
+        if (fuse0) {  // state (zero bids, zero prices) must exist before the fused pass publishes bids
+            constexpr int E8 = Tr<uint8_t>::E;
+            sv.bpc = 1;
+            sv.nchunks = (n + E8 - 1) / E8;
+            sv.npad = sv.nchunks * E8;
+            rc = sv_begin_t<uint8_t>(sv);
             if (rc) return rc;
+        }
+        if ((rc = sv_compress(sv, bpc, &fits, spec, fuse0))) return rc;
+        if (!fits) continue;
+        if (!fuse0) {
+            TD_DISPATCH(sv, sv_begin_t, sv);
+            if (rc) return rc;
+        }
+        for (int r = 0; r < max_rounds; r++) {
+            if (!(r == 0 && sv.fused_bid0)) {
+                TD_DISPATCH(sv, sv_bid_t, sv, r, (unsigned long long *)sv.bid.p);
+                if (rc) return rc;
+            }
             TD_DISPATCH(sv, sv_apply_t, sv, r, (unsigned long long *)sv.bid.p);
             if (rc) return rc;
         }

@@ -23,7 +23,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps({"n": n, "ms": round(dt * 1e3, 3), "total": tot, "ok": tot == 10 * n == dual, "stats": td.last_stats(), "prof": prof}))
     sys.exit(0)
 for n in [16384, 4096, 1000]:
-    for env in [{}, {"TD_PSAP8": "0"}, {"TD_PSAP8": "2"}, {"TD_PSAP8_GRID": "16"}]:
+    for env in [{}, {"TD_FUSE_BID0": "0"}]:
         e = dict(os.environ); e.update(env)
         out = subprocess.run([sys.executable, __file__, "child", str(n)], env=e, capture_output=True, text=True)
         print(env, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-500:], flush=True)
