@@ -85,7 +85,7 @@ enum {
 constexpr int ROW_BITS = 20;
 
 // tunables (env TD_MAX_ROUNDS / TD_TIE_EVICT / TD_LDS_ROUNDS, read once at td_assign)
-int g_max_rounds = 12, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1, g_row_rounds = 2, g_cgrid = 6, g_creg = 1, g_psap_batches = 16, g_psap_min = 12, g_psap_u8 = 0, g_speculate = 1, g_psap8_batches = 1, g_psap8_grid = 64, g_fuse_bid0 = 0;  // fused round 0: measured slower (0.431 vs 0.268+0.085 ms)
+int g_max_rounds = 12, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1, g_row_rounds = 2, g_cgrid = 6, g_creg = 1, g_psap_batches = 16, g_psap_min = 12, g_psap_u8 = 0, g_speculate = 1, g_psap8_batches = 1, g_psap8_grid = 64, g_onewave = 0, g_fuse_bid0 = 0;  // fused round 0: measured slower (0.431 vs 0.268+0.085 ms)
 void read_tunables()
 {
     static bool done = false;
@@ -103,6 +103,7 @@ void read_tunables()
     if (const char *e = getenv("TD_PSAP_U8")) g_psap_u8 = atoi(e) != 0;
     if (const char *e = getenv("TD_SPECULATE")) g_speculate = atoi(e) != 0;
     if (const char *e = getenv("TD_FUSE_BID0")) g_fuse_bid0 = atoi(e) != 0;
+    if (const char *e = getenv("TD_ONEWAVE")) g_onewave = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("TD_PSAP8")) g_psap8_batches = std::max(0, std::min(32, atoi(e)));
     if (const char *e = getenv("TD_PSAP8_GRID")) g_psap8_grid = std::max(1, std::min(192, atoi(e)));
 }
@@ -745,19 +746,21 @@ __device__ __forceinline__ void wave_argmin(PT &key, int &j, int &o, PT &p)
         p = (PT)__builtin_amdgcn_readlane((int)p, L);
         key = (PT)m;
     } else {
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) {
-            const PT ok = shfl_xor_t(key, s);
-            const int oj = __shfl_xor(j, s);
-            const int oo = __shfl_xor(o, s);
-            const PT op = shfl_xor_t(p, s);
-            if (ok < key || (ok == key && oj < j)) {
-                key = ok;
-                j = oj;
-                o = oo;
-                p = op;
-            }
-        }
+        // 64-bit keys (non-negative): three DPP min reductions (high word, low word among the
+        // high-word winners, then j) instead of 36 LDS-routed shuffles
+        const uint32_t hi = (uint32_t)((unsigned long long)key >> 32), lo = (uint32_t)key;
+        const uint32_t mh = wave_umin32(hi);
+        const uint32_t ml = wave_umin32(hi == mh ? lo : 0xFFFFFFFFu);
+        const bool at = (hi == mh) && (lo == ml);
+        const uint32_t jm = wave_umin32(at ? (uint32_t)j : 0xFFFFFFFFu);
+        const unsigned long long b = __ballot(at && (uint32_t)j == jm);
+        const int L = __ffsll((long long)b) - 1;
+        j = (int)jm;
+        o = __builtin_amdgcn_readlane(o, L);
+        const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)p, L);
+        const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)p >> 32), L);
+        p = (PT)(((unsigned long long)phi << 32) | plo);
+        key = (PT)(((unsigned long long)mh << 32) | ml);
     }
 }
 
@@ -1873,6 +1876,13 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
     const int n = sv.n, nchunks = sv.nchunks, npad = sv.npad;
     int CH = 1;
     while (CH * 1024 < nchunks) CH *= 2;
+    // small models: prefer ONE wavefront that owns several chunks per lane over two or four
+    // wavefronts with one chunk each — a single wave needs no barrier / LDS exchange per step
+    if (g_onewave && sizeof(CT) > 1) {
+        int ch1 = 1;
+        while (ch1 * 64 < nchunks) ch1 *= 2;
+        if (ch1 * E <= g_onewave && ch1 <= 16) CH = ch1;
+    }
     int T = (nchunks + CH - 1) / CH;
     T = std::min(1024, std::max(64, ((T + 63) / 64) * 64));
     const size_t st = (size_t)npad * 2 * sizeof(int);  // owner[] + pred[]
