@@ -55,14 +55,78 @@ __device__ __forceinline__ unsigned long long lcm_scan_row(const int32_t *__rest
     return best;
 }
 
+// Narrow copy for the re-scans: code = min(value - base, 255) as one byte per cell (255 also for
+// non-candidates and padding), rows padded to 16 bytes.  A re-scan then streams 16 columns per
+// lane per load instead of one; a row whose free columns all carry code 255 falls back to the
+// exact int32 scan.  base = smallest row minimum (written by k_lcm_rowscan with atomicMin).
+__global__ __launch_bounds__(256) void k_lcm_narrow(int n, int pitch, const int32_t *__restrict__ cost,
+                                                    int64_t cand_limit, const int32_t *__restrict__ base_p,
+                                                    uint8_t *__restrict__ codes)
+{
+    const int32_t base = *base_p;
+    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+        const int32_t *rp = cost + (int64_t)row * n;
+        uint8_t *dst = codes + (size_t)row * pitch;
+        for (int j = threadIdx.x; j < pitch; j += blockDim.x) {
+            uint32_t code = 255u;
+            if (j < n) {
+                const int32_t v = rp[j];
+                const int64_t d = (int64_t)v - (int64_t)base;
+                if ((int64_t)v < cand_limit && d >= 0 && d < 255) code = (uint32_t)d;
+            }
+            dst[j] = (uint8_t)code;
+        }
+    }
+}
+
+// first minimum code among unmasked columns of one narrow row, by one wavefront:
+// returns code << 20 | col  (0xFFFFFFFF when nothing below 255 is left)
+__device__ __forceinline__ uint32_t lcm_scan_narrow(const uint8_t *__restrict__ rp, int nchunks, int lane,
+                                                    const uint32_t *colmask)
+{
+    uint32_t best = 0xFFFFFFFFu;
+    for (int c0 = lane; c0 < nchunks; c0 += 128) {
+        uint4 cv[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (c0 + 64 * u < nchunks) cv[u] = *reinterpret_cast<const uint4 *>(rp + (size_t)(c0 + 64 * u) * 16);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int ch = c0 + 64 * u;
+            if (ch >= nchunks) continue;
+            const uint32_t wmask = colmask[ch >> 1];
+            const uint32_t m16 = (ch & 1) ? (wmask >> 16) : (wmask & 0xFFFFu);
+            const uint32_t wv[4] = {cv[u].x, cv[u].y, cv[u].z, cv[u].w};
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const uint32_t code = (wv[e >> 2] >> (8 * (e & 3))) & 0xFFu;
+                const uint32_t k = (code << 20) | (uint32_t)(ch * 16 + e);
+                const bool ok = !((m16 >> e) & 1u) && code < 255u;
+                best = (ok && k < best) ? k : best;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t ob = __shfl_xor(best, o);
+        best = ob < best ? ob : best;
+    }
+    return best;
+}
+
 __global__ __launch_bounds__(256) void k_lcm_rowscan(int n, const int32_t *__restrict__ cost, int64_t cand_limit,
-                                                     unsigned long long *__restrict__ rowbest)
+                                                     unsigned long long *__restrict__ rowbest, int32_t *__restrict__ base)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int32_t mn = INT_MAX;
     for (int row = blockIdx.x * nw + w; row < n; row += gridDim.x * nw) {
         const unsigned long long b = lcm_scan_row(cost + (int64_t)row * n, n, lane, nullptr, cand_limit);
-        if (lane == 0) rowbest[row] = b;
+        if (lane == 0) {
+            rowbest[row] = b;
+            if (b != LCM_INF) mn = min(mn, lcm_val(b));
+        }
     }
+    if (lane == 0 && mn != INT_MAX) atomicMin(base, mn);
 }
 
 struct LcmOut {
@@ -77,7 +141,8 @@ __global__ __launch_bounds__(1024) void k_lcm_loop(int n, const int32_t *__restr
                                                    unsigned long long *__restrict__ rowbest, int rb_in_lds,
                                                    int32_t *__restrict__ rows,
                                                    int32_t *__restrict__ cols, int *__restrict__ rescan,
-                                                   LcmOut *__restrict__ out)
+                                                   LcmOut *__restrict__ out, const uint8_t *__restrict__ codes,
+                                                   int pitch, const int32_t *__restrict__ base_p)
 {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     // dynamic LDS: [rowbest copy: n x 8 B when it fits] [column mask: (n+31)/32 words]
@@ -149,7 +214,12 @@ __global__ __launch_bounds__(1024) void k_lcm_loop(int n, const int32_t *__restr
         const int nres = s_nres;
         for (int q = w; q < nres; q += nw) {
             const int i = rescan[q];
-            const unsigned long long b = lcm_scan_row(cost + (int64_t)i * n, n, lane, s_colmask, cand_limit);
+            unsigned long long b;
+            const uint32_t nk = codes ? lcm_scan_narrow(codes + (size_t)i * pitch, pitch >> 4, lane, s_colmask) : 0xFFFFFFFFu;
+            if (nk != 0xFFFFFFFFu)
+                b = lcm_key(*base_p + (int32_t)(nk >> 20), (int)(nk & 0xFFFFFu));   // exact: code < 255
+            else
+                b = lcm_scan_row(cost + (int64_t)i * n, n, lane, s_colmask, cand_limit);
             if (lane == 0) rb[i] = b;
         }
         __syncthreads();
@@ -183,6 +253,10 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
     if ((rc = ensure(c.lcm_b, sizeof(int32_t) * 2 * (size_t)n))) return rc;
     if ((rc = ensure(c.lcm_c, sizeof(int32_t) * (size_t)n))) return rc;
     if ((rc = ensure(c.lcm_d, 256))) return rc;
+    const int pitch = ((n + 15) / 16) * 16;
+    const bool narrow = n >= 128;   // below that a row is a single load per lane anyway
+    if (narrow && (rc = ensure(c.cc, (size_t)n * pitch))) return rc;
+    int32_t *d_base = (int32_t *)((char *)c.lcm_d.p + 128);
     const int cap = std::min(n, max_pairs);
     int32_t *d_rows = (int32_t *)c.lcm_b.p, *d_cols = d_rows + n;
     // Java's scan only ever sees cells strictly below big_cost (Simulator.java:529-537)
@@ -190,8 +264,11 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
     const size_t shm_mask = sizeof(uint32_t) * (size_t)((n + 31) / 32);
     {
         ProfScope ps(TD_K_LCM);
+        TD_HIP(hipMemsetD32Async((hipDeviceptr_t)d_base, INT_MAX, 1, c.stream));
         k_lcm_rowscan<<<std::min((n + 3) / 4, c.n_cu * 8), 256, 0, c.stream>>>(n, d_cost, cand_limit,
-                                                                               (unsigned long long *)c.lcm_a.p);
+                                                                               (unsigned long long *)c.lcm_a.p, d_base);
+        if (narrow)
+            k_lcm_narrow<<<std::min(n, c.n_cu * 8), 256, 0, c.stream>>>(n, pitch, d_cost, cand_limit, d_base, (uint8_t *)c.cc.p);
         int T = std::min(1024, std::max(64, ((n + 63) / 64) * 64));
         const int rb_in_lds = ((size_t)n * 8 + shm_mask) <= 96 * 1024;
         const size_t shm = shm_mask + (rb_in_lds ? (size_t)n * 8 : 0);
@@ -199,7 +276,8 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
             (void)hipFuncSetAttribute((const void *)k_lcm_loop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         k_lcm_loop<<<1, T, shm, c.stream>>>(n, d_cost, cand_limit, mask, threshold, stop_value_on, stop_value,
                                             stop_size, sum_below, cap, (unsigned long long *)c.lcm_a.p, rb_in_lds, d_rows, d_cols,
-                                            (int *)c.lcm_c.p, (LcmOut *)c.lcm_d.p);
+                                            (int *)c.lcm_c.p, (LcmOut *)c.lcm_d.p, narrow ? (const uint8_t *)c.cc.p : nullptr,
+                                            pitch, d_base);
     }
     TD_HIP(hipGetLastError());
     TD_HIP(hipMemcpyAsync(c.pinned, c.lcm_d.p, sizeof(LcmOut), hipMemcpyDeviceToHost, c.stream));
