@@ -30,7 +30,7 @@ def build(force=False, verbose=False):
         hipcc = "hipcc"
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
-           "-DTD_BUILDING=1", "-o", LIB] + srcs
+           "-DTD_BUILDING=1", "-DTD_NT=%s" % os.environ.get("TD_NT", "2"), "-o", LIB] + srcs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)

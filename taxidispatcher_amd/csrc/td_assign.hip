@@ -142,6 +142,18 @@ __device__ __forceinline__ void unpack<uint32_t>(const uint4 &v, uint32_t *o)
     o[3] = v.w;
 }
 
+// 16-byte streaming load: TD_NT bit 2 makes the bidding kernels' row stream nontemporal
+__device__ __forceinline__ uint4 load16_stream(const void *p)
+{
+#if defined(TD_NT) && (TD_NT & 4)
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+#else
+    return *reinterpret_cast<const uint4 *>(p);
+#endif
+}
+
 template <typename T>
 __device__ __forceinline__ T shfl_xor_t(T v, int m)
 {
@@ -266,7 +278,15 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nrows, int 
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
             const int q = k * THREADS + tid;
+#if defined(TD_NT) && (TD_NT & 2)
+            if (q < nq) {
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                const v4i t4 = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(s4) + q);
+                v[k] = make_int4(t4.x, t4.y, t4.z, t4.w);
+            }
+#else
             if (q < nq) v[k] = s4[q];
+#endif
         }
         int mn = INT_MAX, mx = INT_MIN;
 #pragma unroll
@@ -457,7 +477,7 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nrows, int
                 int ch = t + rot;
                 if (ch >= nchunks) ch -= nchunks;
                 chs[u] = t < nchunks ? ch : -1;
-                if (t < nchunks) cv[u] = *reinterpret_cast<const uint4 *>(rp + (size_t)ch * E);
+                if (t < nchunks) cv[u] = load16_stream(rp + (size_t)ch * E);
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {

@@ -208,6 +208,11 @@ __global__ void k_cost_scatter_by_id(const int32_t *cab_to, const int32_t *cab_i
     if (thr < 0 || x < thr) cost[(int64_t)ci * n + di] = x;
 }
 
+#ifndef TD_NT
+#define TD_NT 0
+#endif
+static constexpr bool NT_STORES = (TD_NT & 1) != 0;   // bit 0: nontemporal cost stores, bit 1: nontemporal compress loads
+
 // a-10 perf.jl-style uniform instance; thread = 4 cells, one int4 store.
 template <bool VEC4>
 __global__ __launch_bounds__(256) void k_gen_uniform(int n, uint64_t seed, int32_t lo, uint32_t span, int row0,
@@ -227,7 +232,12 @@ __global__ __launch_bounds__(256) void k_gen_uniform(int n, uint64_t seed, int32
         }
         int32_t *dst = cost + (int64_t)r * n + q * 4;
         if (VEC4) {
-            *reinterpret_cast<int4 *>(dst) = make_int4(v[0], v[1], v[2], v[3]);
+            if (NT_STORES) {
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                v4i pk4 = {v[0], v[1], v[2], v[3]};
+                __builtin_nontemporal_store(pk4, reinterpret_cast<v4i *>(dst));
+            } else
+                *reinterpret_cast<int4 *>(dst) = make_int4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; e++)
