@@ -100,6 +100,17 @@ TD_API int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshold, i
            int32_t stop_value, int stop_size, int64_t sum_below, int max_pairs,
            int32_t *rows, int32_t *cols, int32_t *n_pairs, int64_t *total, int32_t *last_min);
 
+/* ---- f-3 pool of two (the step right before the path in every tick) -------------------
+ * Replaces findPool: Simulator.java:681-758 (and pool.c:64-131): every ordered pair (A, B) of
+ * requests is a candidate with cost = min(plan1, plan2) (:693-717); plans are taken in STABLE
+ * order of cost (insertion order A-major, then B) and kept iff neither customer is in an earlier
+ * kept plan (:729-739).  Implemented as the lowest-cost method with symmetric masking on the
+ * n x n pair-cost matrix (same kernels as td_lcm).  Outputs up to n/2 plans in the reference's
+ * order: cust_a[i] picks up cust_b[i]; plan[i] = 1 (CLNT_B_ENDS) iff cost1 < cost2 else 0.
+ */
+TD_API int td_pool2(int n, const int32_t *from, const int32_t *to, const int32_t *dist, int S,
+                    int32_t *cust_a, int32_t *cust_b, int32_t *plan, int32_t *cost, int32_t *n_pairs);
+
 /* ---- a-7 objective evaluation  (greedy_opt.py:21-29 count_sum) ---------------------- */
 TD_API int td_count_sum(int n, const int32_t *cost, const int32_t *row_to_col, int64_t big_cost,
                  int64_t *sum, int32_t *n_real);

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(1024) void k_lcm_loop(int n, const int32_t *__restr
                                                    int32_t *__restrict__ rows,
                                                    int32_t *__restrict__ cols, int *__restrict__ rescan,
                                                    LcmOut *__restrict__ out, const uint8_t *__restrict__ codes,
-                                                   int pitch, const int32_t *__restrict__ base_p)
+                                                   int pitch, const int32_t *__restrict__ base_p, int symmetric)
 {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     // dynamic LDS: [rowbest copy: n x 8 B when it fits] [column mask: (n+31)/32 words]
@@ -201,14 +201,19 @@ __global__ __launch_bounds__(1024) void k_lcm_loop(int n, const int32_t *__restr
         if (tid == 0) {
             rb[r] = LCM_INF;
             s_colmask[c >> 5] |= 1u << (c & 31);
+            if (symmetric) {  // pool of two: both customers leave the game in both roles
+                rb[c] = LCM_INF;
+                s_colmask[r >> 5] |= 1u << (r & 31);
+            }
             s_nres = 0;
         }
         __syncthreads();
         if (stop_size >= 0 && size == stop_size) break;    // Simulator.java:544-545
-        // rows whose cached first minimum sat in column c must be re-scanned
+        // rows whose cached first minimum sat in a column that was just taken must be re-scanned
         for (int i = tid; i < n; i += T) {
             const unsigned long long k = rb[i];
-            if (k != LCM_INF && (int)(uint32_t)k == c) rescan[atomicAdd(&s_nres, 1)] = i;
+            if (k != LCM_INF && ((int)(uint32_t)k == c || (symmetric && (int)(uint32_t)k == r)))
+                rescan[atomicAdd(&s_nres, 1)] = i;
         }
         __syncthreads();
         const int nres = s_nres;
@@ -277,7 +282,7 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
         k_lcm_loop<<<1, T, shm, c.stream>>>(n, d_cost, cand_limit, mask, threshold, stop_value_on, stop_value,
                                             stop_size, sum_below, cap, (unsigned long long *)c.lcm_a.p, rb_in_lds, d_rows, d_cols,
                                             (int *)c.lcm_c.p, (LcmOut *)c.lcm_d.p, narrow ? (const uint8_t *)c.cc.p : nullptr,
-                                            pitch, d_base);
+                                            pitch, d_base, 0);
     }
     TD_HIP(hipGetLastError());
     TD_HIP(hipMemcpyAsync(c.pinned, c.lcm_d.p, sizeof(LcmOut), hipMemcpyDeviceToHost, c.stream));
@@ -293,5 +298,127 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
     if (n_pairs) *n_pairs = o.n_pairs;
     if (total) *total = o.total;
     if (last_min) *last_min = o.last_min;
+    return TD_OK;
+}
+
+
+// =====================================================================================
+// f-3 pool of two (Simulator.java:681-758, pool.c:64-131): every ordered pair (A, B), A != B,
+// is a candidate; cost = min(plan1, plan2); plans are taken in stable order of cost (insertion
+// order A-major, then B) and a plan is kept iff neither customer is in an earlier kept plan.
+// That is the lowest-cost method with SYMMETRIC masking on the n x n pair-cost matrix, so the
+// same two kernels do it: k_lcm_rowscan + k_lcm_loop(symmetric).
+// =====================================================================================
+namespace {
+
+__device__ __forceinline__ int pool_d(const int32_t *dist, int S, int a, int b)
+{
+    return dist ? dist[(int64_t)a * S + b] : (a > b ? a - b : b - a);
+}
+
+// pair cost matrix: pc[A][B] = min(cost1, cost2), diagonal = INT_MAX (never a candidate)
+__global__ __launch_bounds__(256) void k_pool2_cost(int n, const int32_t *__restrict__ from,
+                                                    const int32_t *__restrict__ to, const int32_t *__restrict__ dist,
+                                                    int S, int32_t *__restrict__ pc)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    const int bf = from[b], bt = to[b];
+    for (int a = blockIdx.y; a < n; a += gridDim.y) {
+        const int af = from[a], at = to[a];
+        const int head = pool_d(dist, S, af, bf);
+        const int cost1 = head + pool_d(dist, S, bf, at) + pool_d(dist, S, at, bt);   // Simulator.java:693-695
+        const int cost2 = head + pool_d(dist, S, bf, bt) + pool_d(dist, S, bt, at);   // :697-699
+        pc[(int64_t)a * n + b] = (a == b) ? INT_MAX : (cost1 < cost2 ? cost1 : cost2);
+    }
+}
+
+// plan / cost of the kept pairs (Simulator.java:710-717)
+__global__ void k_pool2_plans(int k, int n, const int32_t *__restrict__ from, const int32_t *__restrict__ to,
+                              const int32_t *__restrict__ dist, int S, const int32_t *__restrict__ ca,
+                              const int32_t *__restrict__ cb, int32_t *__restrict__ plan, int32_t *__restrict__ cost)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const int a = ca[i], b = cb[i];
+    const int af = from[a], at = to[a], bf = from[b], bt = to[b];
+    const int head = pool_d(dist, S, af, bf);
+    const int cost1 = head + pool_d(dist, S, bf, at) + pool_d(dist, S, at, bt);
+    const int cost2 = head + pool_d(dist, S, bf, bt) + pool_d(dist, S, bt, at);
+    plan[i] = cost1 < cost2 ? 1 : 0;   // CLNT_B_ENDS : CLNT_A_ENDS
+    cost[i] = cost1 < cost2 ? cost1 : cost2;
+}
+
+}  // namespace
+
+extern "C" int td_pool2(int n, const int32_t *from, const int32_t *to, const int32_t *dist, int S, int32_t *cust_a,
+                        int32_t *cust_b, int32_t *plan, int32_t *cost, int32_t *n_pairs)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (n_pairs) *n_pairs = 0;
+    if (n < 0) return fail(TD_EINVAL, "n < 0");
+    if (n < 2) return TD_OK;
+    if (!from || !to || !cust_a || !cust_b || !plan || !cost) return fail(TD_EINVAL, "null array");
+    if (dist && S <= 0) return fail(TD_EINVAL, "dist given but S=%d", S);
+    int rc;
+    const void *d_from, *d_to, *d_dist = nullptr;
+    if ((rc = ensure(c.stage_a, sizeof(int32_t) * 2 * (size_t)n))) return rc;
+    if (is_device_ptr(from)) d_from = from;
+    else {
+        TD_HIP(hipMemcpyAsync(c.stage_a.p, from, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c.stream));
+        d_from = c.stage_a.p;
+    }
+    if (is_device_ptr(to)) d_to = to;
+    else {
+        TD_HIP(hipMemcpyAsync((int32_t *)c.stage_a.p + n, to, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c.stream));
+        d_to = (int32_t *)c.stage_a.p + n;
+    }
+    if (dist && (rc = to_device(dist, sizeof(int32_t) * (size_t)S * S, c.stage_c, &d_dist))) return rc;
+    if ((rc = ensure(c.stage_d, sizeof(int32_t) * (size_t)n * n))) return rc;   // pair-cost matrix
+    if ((rc = ensure(c.lcm_a, sizeof(unsigned long long) * (size_t)n))) return rc;
+    if ((rc = ensure(c.lcm_b, sizeof(int32_t) * 4 * (size_t)n))) return rc;
+    if ((rc = ensure(c.lcm_c, sizeof(int32_t) * (size_t)n))) return rc;
+    if ((rc = ensure(c.lcm_d, 256))) return rc;
+    int32_t *pc = (int32_t *)c.stage_d.p;
+    int32_t *d_a = (int32_t *)c.lcm_b.p, *d_b = d_a + n, *d_plan = d_a + 2 * n, *d_cost = d_a + 3 * n;
+    const int pitch = ((n + 15) / 16) * 16;
+    const bool narrow = n >= 128;
+    if (narrow && (rc = ensure(c.cc, (size_t)n * pitch))) return rc;
+    int32_t *d_base = (int32_t *)((char *)c.lcm_d.p + 128);
+    const int64_t cand_limit = (int64_t)INT_MAX;   // the diagonal (INT_MAX) is not a candidate
+    const size_t shm_mask = sizeof(uint32_t) * (size_t)((n + 31) / 32);
+    {
+        ProfScope ps(TD_K_LCM);
+        dim3 g((n + 255) / 256, std::min(n, 1024));
+        k_pool2_cost<<<g, 256, 0, c.stream>>>(n, (const int32_t *)d_from, (const int32_t *)d_to, (const int32_t *)d_dist, S, pc);
+        TD_HIP(hipMemsetD32Async((hipDeviceptr_t)d_base, INT_MAX, 1, c.stream));
+        k_lcm_rowscan<<<std::min((n + 3) / 4, c.n_cu * 8), 256, 0, c.stream>>>(n, pc, cand_limit, (unsigned long long *)c.lcm_a.p, d_base);
+        if (narrow) k_lcm_narrow<<<std::min(n, c.n_cu * 8), 256, 0, c.stream>>>(n, pitch, pc, cand_limit, d_base, (uint8_t *)c.cc.p);
+        int T = std::min(1024, std::max(64, ((n + 63) / 64) * 64));
+        const int rb_in_lds = ((size_t)n * 8 + shm_mask) <= 96 * 1024;
+        const size_t shm = shm_mask + (rb_in_lds ? (size_t)n * 8 : 0);
+        if (shm > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_lcm_loop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        k_lcm_loop<<<1, T, shm, c.stream>>>(n, pc, cand_limit, INT_MAX, -1, 0, 0, -1, (int64_t)INT_MAX, n / 2, (unsigned long long *)c.lcm_a.p,
+                                            rb_in_lds, d_a, d_b, (int *)c.lcm_c.p, (LcmOut *)c.lcm_d.p,
+                                            narrow ? (const uint8_t *)c.cc.p : nullptr, pitch, d_base, 1);
+    }
+    TD_HIP(hipGetLastError());
+    TD_HIP(hipMemcpyAsync(c.pinned, c.lcm_d.p, sizeof(LcmOut), hipMemcpyDeviceToHost, c.stream));
+    TD_HIP(hipStreamSynchronize(c.stream));
+    const int k = ((const LcmOut *)c.pinned)->n_pairs;
+    if (k > 0) {
+        k_pool2_plans<<<(k + 255) / 256, 256, 0, c.stream>>>(k, n, (const int32_t *)d_from, (const int32_t *)d_to,
+                                                             (const int32_t *)d_dist, S, d_a, d_b, d_plan, d_cost);
+        TD_HIP(hipGetLastError());
+        int32_t *outs[4] = {cust_a, cust_b, plan, cost};
+        int32_t *srcs[4] = {d_a, d_b, d_plan, d_cost};
+        for (int q = 0; q < 4; q++)
+            TD_HIP(hipMemcpyAsync(outs[q], srcs[q], sizeof(int32_t) * (size_t)k,
+                                  is_device_ptr(outs[q]) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipStreamSynchronize(c.stream));
+    }
+    if (n_pairs) *n_pairs = k;
     return TD_OK;
 }

@@ -197,6 +197,26 @@ def LCM_simulator(cost, max_non_lcm=600, big_cost=BIG_COST):
     return list(zip(map(int, rows), map(int, cols))), lm
 
 
+def find_pool(frm, to, distances=None):
+    """Simulator.java:681-758 findPool on the GPU: requests given by their from/to stands ->
+    list of (custA, custB, plan, cost) in the order the reference keeps them."""
+    lib = _ffi.lib()
+    frm, to = _ffi.as_i32(frm), _ffi.as_i32(to)
+    n = int(frm.size)
+    if n < 2:
+        return []
+    dptr, S, keep = _dist_arg(distances)
+    a = np.empty(n // 2 + 1, np.int32)
+    b = np.empty(n // 2 + 1, np.int32)
+    plan = np.empty(n // 2 + 1, np.int32)
+    cost = np.empty(n // 2 + 1, np.int32)
+    k = ctypes.c_int32(0)
+    _ffi.check(lib.td_pool2(n, _ffi.addr(frm), _ffi.addr(to), dptr, S, _ffi.addr(a), _ffi.addr(b), _ffi.addr(plan),
+                            _ffi.addr(cost), ctypes.byref(k)))
+    del keep
+    return [(int(a[i]), int(b[i]), int(plan[i]), int(cost[i])) for i in range(k.value)]
+
+
 def count_sum(nn, cost, res, big_cost=BIG_COST):
     """greedy_opt.py:21-29 with positional lists: because cost[taxi][trip] IS
     dist[supply[taxi].to][demand[trip].from] for every real cell, the sum over x==1 cells with

@@ -4,9 +4,11 @@ A from-scratch host harness with the semantics of `Simulator.java` (file:line ci
 so that the committed run log `simulations/simulog_solv.txt` can be replayed: per tick it builds
 the cost matrix, cuts the model with LCM when it is larger than MAX_NON_LCM, applies the pairs,
 re-builds the remainder and solves it to optimality.  The three path operations go through a
-backend object; the product backend is `HipBackend` (the MI355X library).  World bookkeeping
-(cab movement, request intake/drop, pool of two) is plain host code — it is not on the hot path
- and is kept only as far as the golden trace needs it.
+backend object; the product backend is `HipBackend` (the MI355X library), which also runs the
+pool-of-two pre-reduce on the GPU (td_pool2, SURVEY f-3).  World bookkeeping (cab movement,
+request intake/drop) is plain host code — it is not on the hot path and is
+kept only as far as the golden trace needs it; the numpy pool finder below is the restatement
+the oracle-backed replay uses.
 
 Bug-compatible details that the trace depends on are listed in SURVEY.md Appendix A.
 """
@@ -38,6 +40,9 @@ class HipBackend:
 
     def solve(self, cost):
         return self.d.assign(cost)[0]
+
+    def find_pool(self, frm, to):
+        return self.d.find_pool(frm, to, None)
 
 
 def read_demand(path):
@@ -146,6 +151,11 @@ class Simulator:
             return []
         frm = np.array([r[1] for r in temp_demand], np.int64)
         to = np.array([r[2] for r in temp_demand], np.int64)
+        self.m["max_POOL_MEM_size"] = max(self.m["max_POOL_MEM_size"], n * (n - 1))
+        if hasattr(self.be, "find_pool"):      # pool of two on the GPU (td_pool2)
+            out = self.be.find_pool(frm, to)
+            self.m["max_POOL_size"] = max(self.m["max_POOL_size"], len(out))
+            return out
         dAfBf = np.abs(frm[:, None] - frm[None, :])
         cost1 = dAfBf + np.abs(frm[None, :] - to[:, None]) + np.abs(to[:, None] - to[None, :])
         cost2 = dAfBf + np.abs(frm[None, :] - to[None, :]) + np.abs(to[None, :] - to[:, None])

@@ -91,3 +91,39 @@ def test_config5_tick_pipeline_gpu(td):
     t_o, r_o, _, _ = oracle.assign(cost2)
     assert total == t_o == dual
     assert td.count_sum(n2, cost2, r2c) == oracle.count_sum(cost2, r_o)[0]
+
+
+@pytest.mark.gpu
+def test_pool_of_two_gpu_matches_host_restatement(td):
+    """f-3: td_pool2 (symmetric lowest-cost method on the pair-cost matrix) against the numpy
+    restatement of Simulator.java:681-758 used by the oracle-backed replay."""
+    from sim_backend import OracleBackend
+    from taxidispatcher_amd import simulator
+    host = simulator.Simulator(np.zeros((0, 5), np.int64), OracleBackend())
+    rng = np.random.default_rng(8)
+    for n in (2, 3, 17, 128, 500, 1445):
+        frm = rng.integers(0, 50, n)
+        to = rng.integers(0, 50, n)
+        demand = [[i, int(frm[i]), int(to[i]), -1, -1, 0] for i in range(n)]
+        ref = host.find_pool(demand)
+        got = td.find_pool(frm, to)
+        assert got == ref, n
+        assert len(got) == n // 2
+    # general (asymmetric) distance table
+    S = 30
+    dist = rng.integers(0, 40, (S, S)).astype(np.int32)
+    frm = rng.integers(0, S, 200)
+    to = rng.integers(0, S, 200)
+    got = td.find_pool(frm, to, dist)
+    d = dist.astype(np.int64)
+    c1 = d[frm[:, None], frm[None, :]] + d[frm[None, :], to[:, None]] + d[to[:, None], to[None, :]]
+    c2 = d[frm[:, None], frm[None, :]] + d[frm[None, :], to[None, :]] + d[to[None, :], to[:, None]]
+    cost = np.minimum(c1, c2)
+    used, exp = set(), []
+    order = sorted(((int(cost[a, b]), a, b) for a in range(200) for b in range(200) if a != b))
+    for cst, a, b in order:
+        if a in used or b in used:
+            continue
+        used.update((a, b))
+        exp.append((a, b, 1 if c1[a, b] < c2[a, b] else 0, cst))
+    assert got == exp
