@@ -312,6 +312,24 @@ class Simulator:
         count = self.analyze_solution(t, r2c, cost, temp_demand, temp_supply)
         return line + "; OPT count=%d" % count
 
+    # ---- Simulator.java:256-277 printMetrics (wall-clock lines are the caller's: pass them in)
+    def metrics_text(self, total_simul_time=0, max_solver_time=0, max_lcm_time=0, max_pool_time=0):
+        m = self.m
+        lines = ["", "Total customers: %d" % self.d_id.size,
+                 "Total dropped customers: %d" % m["total_dropped"],
+                 "Total pickedup customers: %d" % m["total_pickup_numb"],
+                 "Total customers with assigned cabs: %d" % int((self.d_cab > -1).sum()),
+                 "Total simulation time [secs]: %d" % total_simul_time,
+                 "Total pickup time: %d" % m["total_pickup_time"]]
+        if m["total_pickup_numb"] > 0:
+            lines.append("Avg pickup time: %d" % (m["total_pickup_time"] // m["total_pickup_numb"]))
+        lines += ["Max model size: %d" % m["max_model_size"], "Max solver size: %d" % m["max_solver_size"],
+                  "Max solver time: %d" % max_solver_time, "Max LCM time: %d" % max_lcm_time,
+                  "LCM use count: %d" % m["total_LCM_used"], "Max POOL time: %d" % max_pool_time,
+                  "Max POOL array size: %d" % m["max_POOL_MEM_size"], "Max POOL size: %d" % m["max_POOL_size"],
+                  "Total second customers in POOL: %d" % m["total_second_passengers"]]
+        return "\n".join(lines)
+
     def run(self, t_end=HOURS * 60):
         for t in range(t_end):
             line = self.tick(t)
