@@ -24,8 +24,8 @@ struct Ctx {
     char err[512] = {0};
     // grow-only device workspace, reused across calls (no hipMalloc on the hot path)
     Buf stage_a, stage_b, stage_c, stage_d, stage_out;  // host<->device staging
-    Buf cc;                                             // compressed working copy of the cost matrix
-    Buf price, owner, r2c, bid, pred, rowmin, misc, list;
+    Buf cc;                                             // narrow code matrix of td_lcm / td_pool2
+    Buf misc;                                           // small scratch (td_count_sum)
     Buf lcm_a, lcm_b, lcm_c, lcm_d;
     void *pinned = nullptr;  // small pinned host block for result read-back
     size_t pinned_cap = 0;

@@ -322,8 +322,8 @@ void td_shutdown(void)
     (void)hipSetDevice(c.device);
     (void)hipDeviceSynchronize();
     td_assign_release_workspace();
-    Buf *bufs[] = {&c.stage_a, &c.stage_b, &c.stage_c, &c.stage_d, &c.stage_out, &c.cc, &c.price, &c.owner, &c.r2c,
-                   &c.bid,     &c.pred,    &c.rowmin,  &c.misc,    &c.list,      &c.lcm_a, &c.lcm_b, &c.lcm_c, &c.lcm_d};
+    Buf *bufs[] = {&c.stage_a, &c.stage_b, &c.stage_c, &c.stage_d, &c.stage_out, &c.cc,
+                   &c.misc,    &c.lcm_a,   &c.lcm_b,   &c.lcm_c,   &c.lcm_d};
     for (Buf *b : bufs) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr;
