@@ -162,6 +162,14 @@ def _staged(dist, t):
     return dist.get_backend() == "gloo" and getattr(t, "is_cuda", False)
 
 
+def _fence(t):
+    """RCCL collectives are ordered with torch's current stream only; the library may run on its
+    own stream, so make the result visible to the host side before the next library call."""
+    if getattr(t, "is_cuda", False):
+        import torch
+        torch.cuda.current_stream().synchronize()
+
+
 def all_reduce(dist, t, op):
     if _staged(dist, t):
         c = t.cpu()
@@ -169,6 +177,7 @@ def all_reduce(dist, t, op):
         t.copy_(c)
     else:
         dist.all_reduce(t, op=op)
+        _fence(t)
 
 
 def broadcast(dist, t, src):
@@ -178,6 +187,7 @@ def broadcast(dist, t, src):
         t.copy_(c)
     else:
         dist.broadcast(t, src)
+        _fence(t)
 
 
 def all_gather_equal(dist, t):
@@ -190,6 +200,7 @@ def all_gather_equal(dist, t):
         return [o.to(t.device) for o in out]
     out = [t.new_empty(t.shape) for _ in range(world)]
     dist.all_gather(out, t)
+    _fence(t)
     return out
 
 
