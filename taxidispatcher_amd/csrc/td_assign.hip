@@ -1801,9 +1801,10 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false, bool bid0 = fa
         // comes back with the final read-back and a wrong guess is simply redone one width up
         *fits = true;
     } else {
-        TD_HIP(hipMemcpyAsync(c.pinned, ctl, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipMemcpyAsync(c.pinned, ctl, 8 * sizeof(int), hipMemcpyDeviceToHost, c.stream));
         TD_HIP(hipStreamSynchronize(c.stream));
-        *fits = (((int *)c.pinned)[0] == 0);
+        *fits = (((int *)c.pinned)[CTL_FLAG] == 0);
+        if (!*fits) c.stats[6] = (int64_t)(((const unsigned long long *)((int *)c.pinned + CTL_RANGE))[0]);
     }
     if (*fits) {
         sv.bpc = (int)sizeof(CT);
@@ -2102,6 +2103,10 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     for (int bpc : {1, 2, 4}) {
         bool fits = false;
         if (known_range > 65534 && bpc == 2) continue;  // u16 cannot hold it either
+        // the packed bid key keeps (price << 20 | row): prices stay below n * range
+        if (known_range >= 0 && (double)(known_range + 1) * (double)(n + 1) >= 4.0e12)
+            return fail(TD_ERANGE, "row cost range %lld with n=%d overflows the packed bid key (price < 2^43)",
+                        (long long)known_range, n);
         // u8 is tried speculatively (no host round trip in the common case)
         const bool spec = (bpc == 1) && g_speculate;
         const bool fuse0 = spec && g_fuse_bid0 && g_creg && (n % 4 == 0) && n / 4 <= 256 * 16 && (((uintptr_t)sv.d_cost & 15) == 0);
@@ -2114,7 +2119,10 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
             if (rc) return rc;
         }
         if ((rc = sv_compress(sv, bpc, &fits, spec, fuse0))) return rc;
-        if (!fits) continue;
+        if (!fits) {
+            known_range = c.stats[6];
+            continue;
+        }
         if (!fuse0) {
             TD_DISPATCH(sv, sv_begin_t, sv);
             if (rc) return rc;

@@ -363,3 +363,21 @@ def test_assign_multi_chunk_finisher_paths(td, n, width):
         assert total == 10 * (n - 1) + (5000 if width == 2 else 250000)
     del cost
     torch.cuda.empty_cache()
+
+
+def test_range_guard(td):
+    """Costs spanning the whole int32 range are solved exactly while n * range fits the packed bid
+    key and refused loudly (TD_ERANGE) beyond it — never a silently wrong answer."""
+    rng = np.random.default_rng(6)
+    n = 900
+    c = rng.integers(-2**31, 2**31 - 1, (n, n)).astype(np.int32)
+    r2c, total, dual = td.assign(c, want_dual=True)           # 900 * 2^32 = 3.9e12 < 4e12: still fits
+    assert total == oracle.assign(c)[0] == dual
+    n = 1200
+    c = rng.integers(-2**31, 2**31 - 1, (n, n)).astype(np.int32)
+    with pytest.raises(td.TdError, match="overflows the packed bid key"):
+        td.assign(c)
+    # the same size with a narrower range is fine
+    c = rng.integers(0, 10**6, (n, n)).astype(np.int32)
+    r2c, total = td.assign(c)
+    assert total == oracle.assign(c)[0]
