@@ -85,7 +85,9 @@ enum {
 constexpr int ROW_BITS = 20;
 
 // tunables (env TD_MAX_ROUNDS / TD_TIE_EVICT / TD_LDS_ROUNDS, read once at td_assign)
-int g_max_rounds = 12, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1, g_row_rounds = 2, g_cgrid = 6, g_creg = 1, g_psap_batches = 16, g_psap_min = 12, g_psap_u8 = 0, g_speculate = 1, g_psap8_batches = 1, g_psap8_grid = 64, g_onewave = 0, g_fuse_bid0 = 0;  // fused round 0: measured slower (0.431 vs 0.268+0.085 ms)
+int g_max_rounds = 12, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1, g_row_rounds = 2, g_cgrid = 6, g_creg = 1, g_psap_batches = 16, g_psap_min = 12, g_psap_u8 = 0, g_speculate = 1, g_psap8_batches = 1, g_psap8_grid = 64, g_onewave = 0, g_solver_eps = 0, g_eps_theta = 8, g_fuse_bid0 = 0;
+long long g_eps0_mult = 4;
+int g_unused_pad_ = 0;  // fused round 0: measured slower (0.431 vs 0.268+0.085 ms)
 void read_tunables()
 {
     static bool done = false;
@@ -103,6 +105,9 @@ void read_tunables()
     if (const char *e = getenv("TD_PSAP_U8")) g_psap_u8 = atoi(e) != 0;
     if (const char *e = getenv("TD_SPECULATE")) g_speculate = atoi(e) != 0;
     if (const char *e = getenv("TD_FUSE_BID0")) g_fuse_bid0 = atoi(e) != 0;
+    if (const char *e = getenv("TD_SOLVER")) g_solver_eps = (strcmp(e, "eps") == 0);
+    if (const char *e = getenv("TD_EPS0_MULT")) g_eps0_mult = std::max(0ll, atoll(e));
+    if (const char *e = getenv("TD_EPS_THETA")) g_eps_theta = std::max(2, atoi(e));
     if (const char *e = getenv("TD_ONEWAVE")) g_onewave = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("TD_PSAP8")) g_psap8_batches = std::max(0, std::min(32, atoi(e)));
     if (const char *e = getenv("TD_PSAP8_GRID")) g_psap8_grid = std::max(1, std::min(192, atoi(e)));
@@ -432,20 +437,23 @@ __global__ void k_init_state(int n, int npad, int nrows, PT *pk, PT padkey, int 
 // =====================================================================================
 // k_bid: one wavefront per unassigned row
 // =====================================================================================
-template <typename CT, bool LDSP>
+// EPSM = true: the literal eps-scaling auction of the north star (comparison mode, TD_SOLVER=eps):
+// costs scaled by kscale = n + 1, every bid raises the price by (second - best) + eps, no tie rule.
+template <typename CT, bool LDSP, bool EPSM = false>
 __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nrows, int row0, int nchunks,
                                                           const CT *__restrict__ cc,
                                                           const typename Tr<CT>::PT *__restrict__ pk,
                                                           const int *__restrict__ r2c,
                                                           unsigned long long *__restrict__ bid,
-                                                          const int *__restrict__ ctl, int round, int tie_evict)
+                                                          const int *__restrict__ ctl, int round, int tie_evict,
+                                                          long long kscale = 1, long long eps = 0)
 {
     using PT = typename Tr<CT>::PT;
     constexpr int E = Tr<CT>::E;
     constexpr int U = 4;  // 16-byte row chunks in flight per lane
     extern __shared__ __align__(16) unsigned char smem[];
     if (ctl[CTL_FLAG]) return;  // speculated storage width did not fit: the host redoes the solve
-    if (round > 0 && ctl[CTL_PROG + round - 1] == 0) return;  // previous round placed no bid: converged
+    if (!EPSM && round > 0 && ctl[CTL_PROG + round - 1] == 0) return;  // previous round placed no bid: converged
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const size_t pitch = (size_t)nchunks * E;
     const PT *P = pk;
@@ -502,7 +510,7 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nrows, int
                 }
 #pragma unroll
                 for (int e = 0; e < E; e++) {
-                    const PT key = (PT)(2 * (PT)c[e]) + pv[e];  // 2*(cost+price) + owned
+                    const PT key = (EPSM ? (PT)(2 * (PT)c[e] * (PT)kscale) : (PT)(2 * (PT)c[e])) + pv[e];  // 2*(cost+price) + owned
                     const bool lt = key < k1;
                     const PT mx = key > k1 ? key : k1;
                     k2 = k2 < mx ? k2 : mx;
@@ -540,12 +548,25 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nrows, int
             // A tie on an owned column raises no price.  With tie_evict the row still takes the
             // column (complementary slackness stays exact, the previous owner re-bids next round
             // and usually finds a free tied column); otherwise it is left to the finisher.
-            if (j1 < n && (!(owned && inc == 0) || tie_evict)) {
-                const PT newp = (P[j1] >> 1) + inc;
+            if (j1 < n && (EPSM || !(owned && inc == 0) || tie_evict)) {
+                const PT newp = (P[j1] >> 1) + inc + (EPSM ? (PT)eps : (PT)0);
                 atomicMax(&bid[j1], ((unsigned long long)newp << ROW_BITS) | (unsigned long long)(row + 1));
             }
         }
     }
+}
+
+// reset of the assignment between eps phases (prices are kept)
+template <typename PT>
+__global__ void k_eps_reset(int n, int nrows, PT *pk, int *owner, int *r2c, int *ctl)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) {
+        pk[j] = (PT)((pk[j] >> 1) << 1);
+        owner[j] = -1;
+    }
+    if (j < nrows) r2c[j] = -1;
+    if (j >= CTL_PROG && j < CTL_WORDS) ctl[j] = 0;
 }
 
 // k_bid_row: the same bidding round with one WORKGROUP (256 threads) per unassigned row — every
@@ -660,7 +681,7 @@ __global__ __launch_bounds__(256) void k_assign(int n, int nrows, int row0, unsi
                                                 int *__restrict__ ctl, int round)
 {
     if (ctl[CTL_FLAG]) return;
-    if (round > 0 && ctl[CTL_PROG + round - 1] == 0) return;
+    if (round > 0 && round < 60 && ctl[CTL_PROG + round - 1] == 0) return;   // round >= 60: eps mode, always apply
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     int cnt = 0;
     if (j < n) {
@@ -684,7 +705,7 @@ __global__ __launch_bounds__(256) void k_assign(int n, int nrows, int row0, unsi
     }
     const unsigned long long m = __ballot(cnt);
     if ((threadIdx.x & 63) == 0 && m) {
-        atomicAdd(&ctl[CTL_PROG + round], (int)__popcll(m));
+        if (round < 60) atomicAdd(&ctl[CTL_PROG + round], (int)__popcll(m));
     }
 }
 
@@ -2015,6 +2036,47 @@ int sv_totals_t(Solver &sv, bool want_dual)
     return TD_OK;
 }
 
+// The north star's literal algorithm, kept as a measured comparison (TD_SOLVER=eps): Bertsekas
+// eps-scaling Jacobi auction, costs scaled by n+1, eps from eps0 down to 1 by a factor theta;
+// the eps = 1 phase ends with the exact optimum.  Each phase resets the assignment, keeps the
+// prices and bids until every row is assigned; the host polls the free-row count every 8 rounds.
+template <typename CT>
+int sv_solve_eps_t(Solver &sv, long long eps0_mult, int theta, int64_t *rounds_out, int64_t *phases_out)
+{
+    Ctx &c = ctx();
+    using PT = typename Tr<CT>::PT;
+    const int n = sv.n;
+    const long long K = (long long)n + 1;
+    long long eps = eps0_mult > 0 ? K * eps0_mult : 1;
+    int64_t rounds = 0, phases = 0;
+    unsigned long long *keys = (unsigned long long *)sv.bid.p;
+    for (;;) {
+        phases++;
+        k_eps_reset<PT><<<(std::max(n, (int)CTL_WORDS) + 255) / 256, 256, 0, c.stream>>>(n, sv.nrows, (PT *)sv.price.p, (int *)sv.owner.p,
+                                                                                       (int *)sv.r2c.p, (int *)sv.misc.p);
+        for (;;) {
+            for (int r = 0; r < 8; r++) {
+                k_bid<CT, false, true><<<(sv.nrows + 3) / 4, 256, 0, c.stream>>>(n, sv.nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p,
+                                                                               (const PT *)sv.price.p, (const int *)sv.r2c.p, keys,
+                                                                               (const int *)sv.misc.p, 60, 1, K, eps);
+                k_assign<PT><<<(n + 255) / 256, 256, 0, c.stream>>>(n, sv.nrows, sv.row0, keys, (PT *)sv.price.p, (int *)sv.owner.p,
+                                                                   (int *)sv.r2c.p, (int *)sv.misc.p, 60);
+            }
+            rounds += 8;
+            k_freelist<<<1, 1024, 0, c.stream>>>(n, (const int *)sv.r2c.p, (int *)sv.list.p, (int *)sv.misc.p);
+            TD_HIP(hipMemcpyAsync(c.pinned, (int *)sv.misc.p + CTL_NFREE, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+            TD_HIP(hipStreamSynchronize(c.stream));
+            if (((int *)c.pinned)[0] == 0) break;
+            if (rounds > 4000000) return fail(TD_EINTERNAL, "eps auction did not converge in 4M rounds");
+        }
+        if (eps == 1) break;
+        eps = std::max<long long>(1, eps / theta);
+    }
+    *rounds_out = rounds;
+    *phases_out = phases;
+    return TD_OK;
+}
+
 #define TD_DISPATCH(sv, CALL, ...)                                  \
     do {                                                            \
         switch ((sv).bpc) {                                         \
@@ -2126,6 +2188,24 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         if (!fuse0) {
             TD_DISPATCH(sv, sv_begin_t, sv);
             if (rc) return rc;
+        }
+        if (g_solver_eps) {
+            int64_t er = 0, ep = 0;
+            TD_DISPATCH(sv, sv_solve_eps_t, sv, g_eps0_mult, g_eps_theta, &er, &ep);
+            if (rc) return rc;
+            TD_DISPATCH(sv, sv_totals_t, sv, false);
+            if (rc) return rc;
+            int flag = 0;
+            if ((rc = sv_readback(sv, &tot, &dual, 0, spec ? &flag : nullptr))) return rc;
+            if (spec && flag) {
+                known_range = c.stats[6];
+                continue;
+            }
+            dual = tot;   // exact by the eps < 1/n argument; no certificate pass in this mode
+            c.stats[0] = er;
+            c.stats[1] = ep;
+            solved = true;
+            break;
         }
         for (int r = 0; r < max_rounds; r++) {
             if (!(r == 0 && sv.fused_bid0)) {
