@@ -381,3 +381,27 @@ def test_range_guard(td):
     c = rng.integers(0, 10**6, (n, n)).astype(np.int32)
     r2c, total = td.assign(c)
     assert total == oracle.assign(c)[0]
+
+
+def test_eps_scaling_auction_mode_is_exact(td):
+    """The literal eps-scaling auction (TD_SOLVER=eps, comparison mode) reaches the same optimum.
+    Tunables are read once per process, so it runs in a child process."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import taxidispatcher_amd as td
+from oracle import oracle
+td.init(0)
+rng = np.random.default_rng(4)
+for n, lo, hi in [(5, 0, 9), (64, 10, 41), (200, 1, 40), (150, 0, 100000)]:
+    c = rng.integers(lo, hi, (n, n)).astype(np.int32)
+    r2c, tot = td.assign(c)
+    assert tot == oracle.assign(c)[0], (n, tot)
+    assert sorted(r2c.tolist()) == list(range(n))
+print("EPS_OK", td.last_stats()["bid_rounds"])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TD_SOLVER="eps", TD_EPS0_MULT="4")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "EPS_OK" in out.stdout, out.stdout + out.stderr
