@@ -37,10 +37,15 @@ def shard_bounds(n, world, rank):
 class HipShard:
     """One rank's rows on its GPU, through the C ABI (td_shard_*)."""
 
-    def __init__(self, n, row0, nrows, cost_rows):
+    def __init__(self, n, row0, nrows, cost_rows, share_torch_stream=True):
         import torch
         self.torch = torch
         self.lib = _ffi.lib()
+        # Run the library on torch's current stream: RCCL collectives are ordered with that stream,
+        # so bid -> all_reduce -> apply needs no host synchronisation at all.
+        self.shared_stream = bool(share_torch_stream)
+        if self.shared_stream:
+            _ffi.check(self.lib.td_set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
         self.n, self.row0, self.nrows = n, row0, nrows
         self._cost = cost_rows  # keep alive: the library reads it again for the total
         h = ctypes.c_void_p()
@@ -72,11 +77,13 @@ class HipShard:
 
     def bid(self, rnd, keys):
         _ffi.check(self.lib.td_shard_bid(self.h, rnd, keys.data_ptr()))
-        _ffi.check(self.lib.td_synchronize())  # the collective runs on torch's stream
+        if not self.shared_stream:
+            _ffi.check(self.lib.td_synchronize())  # the collective runs on torch's stream
 
     def apply(self, rnd, keys):
         _ffi.check(self.lib.td_shard_apply(self.h, rnd, keys.data_ptr()))
-        _ffi.check(self.lib.td_synchronize())
+        if not self.shared_stream:
+            _ffi.check(self.lib.td_synchronize())
 
     # -- finisher support
     def export_handle(self):
@@ -162,10 +169,14 @@ def _staged(dist, t):
     return dist.get_backend() == "gloo" and getattr(t, "is_cuda", False)
 
 
+_NEED_FENCE = True
+
+
 def _fence(t):
-    """RCCL collectives are ordered with torch's current stream only; the library may run on its
-    own stream, so make the result visible to the host side before the next library call."""
-    if getattr(t, "is_cuda", False):
+    """RCCL collectives are ordered with torch's current stream only; when the library runs on its
+    own stream the result must be complete before the next library call (HipShard with
+    share_torch_stream=True makes this unnecessary)."""
+    if _NEED_FENCE and getattr(t, "is_cuda", False):
         import torch
         torch.cuda.current_stream().synchronize()
 
@@ -207,10 +218,12 @@ def all_gather_equal(dist, t):
 def solve_sharded(shard, dist, rounds=DEFAULT_ROUNDS, want_dual=False, use_ipc=None):
     """Collective part of the sharded solve; `shard` implements the HipShard interface and `dist`
     is torch.distributed (initialised). Returns (local row_to_col, total[, dual])."""
+    global _NEED_FENCE
     world, rank = dist.get_world_size(), dist.get_rank()
     n = shard.n
     _, _, rps = shard_bounds(n, world, rank)
     MIN, MAX, SUM = dist.ReduceOp.MIN, dist.ReduceOp.MAX, dist.ReduceOp.SUM
+    _NEED_FENCE = not getattr(shard, "shared_stream", False)
     # 1. agree on the storage width (every rank must use the same one)
     for width in (1, 2, 4):
         flag = shard.scalar_tensor([1 if shard.compress(width) else 0])

@@ -1,0 +1,24 @@
+"""One-off stress: many random instances of all families against the oracle (dev tool)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import taxidispatcher_amd as td
+from oracle import oracle
+from test_gpu_parity import make_instance
+td.init(0)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 120
+cnt = bad = 0
+while time.time() < t_end:
+    kind = ["g1", "g4", "g2", "g3", "wide", "neg", "const"][int(rng.integers(0, 7))]
+    n = int(rng.integers(2, 1400)) if kind not in ("g2", "wide") else int(rng.integers(2, 700))
+    c = make_instance(kind, n, rng)
+    r2c, tot, dual = td.assign(c, want_dual=True)
+    ref = oracle.assign(c)[0]
+    ok = tot == ref == dual and sorted(r2c.tolist()) == list(range(n)) and int(c[np.arange(n), r2c].astype(np.int64).sum()) == tot
+    cnt += 1
+    if not ok:
+        bad += 1
+        print("FAIL", kind, n, tot, ref, dual, td.last_stats(), flush=True)
+print("stress: %d instances, %d failures" % (cnt, bad))
