@@ -1472,8 +1472,47 @@ __global__ __launch_bounds__(1024) void k_psearch(int n, int nchunks, const Shar
         bj -= (bj >= npad) ? npad : 0;
         const PT bd = bk >> 1;
         if (!(bk & 1)) {
+            // A free column is at the frontier distance.  Usually a whole class of free columns
+            // is tied there (dummy columns of a simulator model): take the k-th of them, k spread
+            // over the searches of the batch, so that concurrent searches end in DIFFERENT columns
+            // instead of rejecting each other at commit.
+            int mycnt = 0;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const bool tie = ((valid >> e) & 1u) && !((scanned >> e) & 1u) && !((owned >> e) & 1u) && d[e] == bd;
+                mycnt += tie ? 1 : 0;
+            }
+            int incl = mycnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            if (lane == 63) s_ro[par][w] = incl;   // reuse the exchange slots
+            __syncthreads();
+            int base = 0, total = 0;
+            for (int q = 0; q < nw; q++) {
+                const int cw = s_ro[par][q];
+                base += (q < w) ? cw : 0;
+                total += cw;
+            }
+            const int target = (int)(((uint64_t)(((uint32_t)b + 1u) * 0x9E3779B1u) * (uint64_t)total) >> 32);
+            const int lo = base + incl - mycnt;
+            if (target >= lo && target < lo + mycnt) {
+                int skip = target - lo;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const bool tie = ((valid >> e) & 1u) && !((scanned >> e) & 1u) && !((owned >> e) & 1u) && d[e] == bd;
+                    if (tie) {
+                        if (skip == 0) s_rj[par ^ 1][0] = jbase + e;
+                        skip--;
+                    }
+                }
+            }
+            __syncthreads();
             mind = bd;
-            endcol = bj;
+            endcol = (total > 0) ? s_rj[par ^ 1][0] : bj;
+            par ^= 1;
             break;
         }
         if (steps >= PS_CAP) {  // too long for a speculative record
