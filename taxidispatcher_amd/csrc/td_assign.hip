@@ -875,10 +875,43 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab
     long long steps = 0;
     int par = 0;
     bool bad = false;
+    // own prices stay in registers for the whole kernel when they fit (PREG): a thread is the
+    // only writer of its columns' prices, so global memory sees them once, at the end
+    PT preg[PREG ? NV : 1];
+    if (PREG) {
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+            const int ch = q * T + tid;
+#pragma unroll
+            for (int e = 0; e < E; e++) preg[q * E + e] = (ch < nchunks) ? P[ch * E + e] : (PT)0;
+        }
+    }
+    // software prefetch of the NEXT free row (its id and its 16-byte chunks) behind the current search
+    int fnext = nfree > 0 ? list[0] : 0;
+    uint4 cvn[CH];
+    if (nfree > 0) {
+        const CT *nrow = shard_row<CT>(tab, fnext, pitch);
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+            const int ch = q * T + tid;
+            if (ch < nchunks) cvn[q] = *reinterpret_cast<const uint4 *>(nrow + (size_t)ch * E);
+        }
+    }
     for (int fi = 0; fi < nfree && !bad; fi++) {
-        const int f = list[fi];
+        const int f = fnext;
+        uint4 cvf[CH];
+#pragma unroll
+        for (int q = 0; q < CH; q++) cvf[q] = cvn[q];
+        if (fi + 1 < nfree) {
+            fnext = list[fi + 1];
+            const CT *nrow = shard_row<CT>(tab, fnext, pitch);
+#pragma unroll
+            for (int q = 0; q < CH; q++) {
+                const int ch = q * T + tid;
+                if (ch < nchunks) cvn[q] = *reinterpret_cast<const uint4 *>(nrow + (size_t)ch * E);
+            }
+        }
         PT d[NV];
-        PT preg[PREG ? NV : 1];
         int ownr[PREG ? NV : 1];
         unsigned long long scanned = padmask;
         // bit set <=> the column has an owner (or does not exist).  Folded into the argmin key
@@ -887,35 +920,27 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab
         // reaches the frontier distance instead of scanning the whole tie class.
         unsigned long long ownedmask = padmask;
         // distances from the free row f (the row dual of f is a constant shift: left out)
-        const CT *frow = shard_row<CT>(tab, f, pitch);
 #pragma unroll
         for (int q = 0; q < CH; q++) {
             const int ch = q * T + tid;
             if (ch < nchunks) {
-                const uint4 cv = *reinterpret_cast<const uint4 *>(frow + (size_t)ch * E);
                 uint32_t c[E];
-                unpack<CT>(cv, c);
+                unpack<CT>(cvf[q], c);
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     const int j = ch * E + e;
-                    const PT p = P[j];
+                    const PT p = PREG ? preg[q * E + e] : P[j];
                     const int o = OWN[j];
-                    if (PREG) {
-                        preg[q * E + e] = p;
-                        ownr[q * E + e] = o;
-                    }
+                    if (PREG) ownr[q * E + e] = o;
                     if (o != -1) ownedmask |= 1ull << (q * E + e);
                     d[q * E + e] = (PT)c[e] + p;
-                    PRED[j] = f;
+                    PRED[j] = -1;   // predecessor COLUMN; -1 = reached from the root row
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     d[q * E + e] = KMAX >> 2;
-                    if (PREG) {
-                        preg[q * E + e] = 0;
-                        ownr[q * E + e] = -2;
-                    }
+                    if (PREG) ownr[q * E + e] = -2;
                 }
             }
         }
@@ -993,7 +1018,7 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab
                         const bool ok = !((scanned >> (q * E + e)) & 1ull);
                         if (ok && h < d[q * E + e]) {
                             d[q * E + e] = h;
-                            PRED[j] = o;
+                            PRED[j] = bj;
                         }
                     }
                 }
@@ -1011,26 +1036,39 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab
             for (int e = 0; e < E; e++) {
                 if ((upd >> (q * E + e)) & 1ull) {
                     const int j = (q * T + tid) * E + e;
-                    const PT p = PREG ? preg[q * E + e] : P[j];
-                    P[j] = p + (mind - d[q * E + e]);
+                    if (PREG)
+                        preg[q * E + e] += mind - d[q * E + e];
+                    else
+                        P[j] = P[j] + (mind - d[q * E + e]);
                 }
             }
         }
         __syncthreads();
-        if (tid == 0) {  // flip the path
+        if (tid == 0) {  // flip the path: column j goes to the (old) owner of its predecessor column
             int j = endcol;
             for (int hop = 0; hop <= n; hop++) {
-                const int i = PRED[j];
+                const int pc = PRED[j];
+                const int i = (pc < 0) ? f : OWN[pc];
                 OWN[j] = i;
-                const int jn = r2c[i];
-                r2c[i] = j;
-                j = jn;
-                if (i == f) break;
+                r2c[i] = j;   // store only: no global load on the walk
+                if (pc < 0) break;
+                j = pc;
             }
         }
         __syncthreads();
     }
     __syncthreads();
+    if (PREG) {
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+            const int ch = q * T + tid;
+            if (ch < nchunks) {
+#pragma unroll
+                for (int e = 0; e < E; e++) P[ch * E + e] = preg[q * E + e];
+            }
+        }
+        __syncthreads();
+    }
     for (int j = tid; j < npad; j += T) {
         pk[j] = (PT)(P[j] << 1) | (PT)1;
         if (LDSST && j < n) owner_g[j] = OWN[j];
