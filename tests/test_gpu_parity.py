@@ -417,3 +417,20 @@ def test_deterministic_output(td):
         for _ in range(4):
             again, t1 = td.assign(c)
             assert t1 == t0 and np.array_equal(first, again), (kind, n)
+
+
+def test_n65536_full_size_single_gpu(td):
+    """BASELINE configs[3] size on ONE MI355X (16 GiB int32 + 4 GiB narrow copy fit 288 GB): the
+    perf.jl instance at N = 65 536, optimum 10*N by the row-minimum bound, certificate on device."""
+    import torch
+    from taxidispatcher_amd import _ffi
+    n = 65536
+    cost = torch.empty((n, n), dtype=torch.int32, device="cuda")
+    _ffi.check(_ffi.lib().td_gen_uniform(n, 2, 10, 40, 0, n, cost.data_ptr()))
+    r2c, total, dual = td.assign(cost, n, want_dual=True)
+    assert total == 10 * n == dual
+    assert np.array_equal(np.sort(r2c), np.arange(n))
+    idx = torch.from_numpy(r2c.astype(np.int64)).cuda()
+    assert int(cost[torch.arange(n, device="cuda"), idx].max().item()) == 10
+    del cost
+    torch.cuda.empty_cache()
