@@ -85,7 +85,7 @@ enum {
 constexpr int ROW_BITS = 20;
 
 // tunables (env TD_MAX_ROUNDS / TD_TIE_EVICT / TD_LDS_ROUNDS, read once at td_assign)
-int g_max_rounds = 12, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1, g_row_rounds = 2, g_cgrid = 6, g_creg = 1, g_psap_batches = 16, g_psap_min = 12, g_psap_u8 = 0, g_speculate = 1, g_psap8_batches = 1, g_psap8_grid = 64, g_onewave = 0, g_solver_eps = 0, g_eps_theta = 8, g_fuse_bid0 = 0;
+int g_max_rounds = 12, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1, g_row_rounds = 2, g_cgrid = 6, g_creg = 1, g_psap_batches = 16, g_psap_min = 12, g_psap_u8 = 0, g_speculate = 1, g_psap8_batches = 1, g_psap8_grid = 64, g_onewave = 0, g_lds_grid = 1, g_solver_eps = 0, g_eps_theta = 8, g_fuse_bid0 = 0;
 long long g_eps0_mult = 4;
 int g_unused_pad_ = 0;  // fused round 0: measured slower (0.431 vs 0.268+0.085 ms)
 void read_tunables()
@@ -105,6 +105,7 @@ void read_tunables()
     if (const char *e = getenv("TD_PSAP_U8")) g_psap_u8 = atoi(e) != 0;
     if (const char *e = getenv("TD_SPECULATE")) g_speculate = atoi(e) != 0;
     if (const char *e = getenv("TD_FUSE_BID0")) g_fuse_bid0 = atoi(e) != 0;
+    if (const char *e = getenv("TD_LDS_GRID")) g_lds_grid = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("TD_SOLVER")) g_solver_eps = (strcmp(e, "eps") == 0);
     if (const char *e = getenv("TD_EPS0_MULT")) g_eps0_mult = std::max(0ll, atoll(e));
     if (const char *e = getenv("TD_EPS_THETA")) g_eps_theta = std::max(2, atoi(e));
@@ -1950,7 +1951,7 @@ int sv_bid_t(Solver &sv, int r, unsigned long long *keys)
     if (can_lds && r < g_lds_rounds) {
         if (lds_prices > 48 * 1024)
             (void)hipFuncSetAttribute((const void *)k_bid<CT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prices);
-        const int grid = std::min((nrows + 15) / 16, c.n_cu);
+        const int grid = std::min((nrows + 15) / 16, c.n_cu * g_lds_grid);
         k_bid<CT, true><<<grid, 1024, lds_prices, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
                                                               (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict);
     } else if (r >= g_row_rounds) {

@@ -22,8 +22,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         if cnt.value: prof[name] = round(ms.value, 3)
     print(json.dumps({"n": n, "ms": round(dt * 1e3, 3), "total": tot, "ok": tot == 10 * n == dual, "stats": td.last_stats(), "prof": prof}))
     sys.exit(0)
-for n in [16384, 4096, 1000]:
-    for env in [{}, {"TD_FUSE_BID0": "0"}]:
+for n in [16384]:
+    for env in [{}, {"TD_LDS_GRID": "2"}, {"TD_LDS_GRID": "4"}, {"TD_LDS_ROUNDS": "0"}, {"TD_LDS_ROUNDS": "2"}, {"TD_LDS_ROUNDS": "2", "TD_LDS_GRID": "2"}, {"TD_ROW_ROUNDS": "1"}]:
         e = dict(os.environ); e.update(env)
         out = subprocess.run([sys.executable, __file__, "child", str(n)], env=e, capture_output=True, text=True)
         print(env, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-500:], flush=True)
