@@ -85,9 +85,26 @@ enum {
 constexpr int ROW_BITS = 20;
 
 // tunables (env TD_MAX_ROUNDS / TD_TIE_EVICT / TD_LDS_ROUNDS, read once at td_assign)
-int g_max_rounds = 12, g_tie_evict = 1, g_lds_rounds = 1, g_sap8 = 1, g_row_rounds = 2, g_cgrid = 6, g_creg = 1, g_psap_batches = 16, g_psap_min = 12, g_psap_u8 = 0, g_speculate = 1, g_psap8_batches = 1, g_psap8_grid = 64, g_onewave = 0, g_lds_grid = 1, g_solver_eps = 0, g_eps_theta = 8, g_fuse_bid0 = 0;
-long long g_eps0_mult = 4;
-int g_unused_pad_ = 0;  // fused round 0: measured slower (0.431 vs 0.268+0.085 ms)
+// defaults are the measured best on MI355X (tools/gpu_sweep.py); every one has an env override
+int g_max_rounds = 12;      // TD_MAX_ROUNDS    bidding rounds launched (converged rounds exit on the device)
+int g_tie_evict = 1;        // TD_TIE_EVICT     rounds >= 1: a tie on owned columns still takes the column
+int g_lds_rounds = 1;       // TD_LDS_ROUNDS    first rounds that stage the price vector in LDS
+int g_lds_grid = 1;         // TD_LDS_GRID      workgroups per CU of the LDS-staged bidding kernel
+int g_row_rounds = 2;       // TD_ROW_ROUNDS    from this round on: one workgroup per row (k_bid_row)
+int g_cgrid = 6;            // TD_CGRID         workgroups per CU of the compress pass
+int g_creg = 1;             // TD_CREG          register-resident compress kernel
+int g_speculate = 1;        // TD_SPECULATE     try u8 storage without waiting for the range flag
+int g_fuse_bid0 = 0;        // TD_FUSE_BID0     round 0 inside the compress pass: measured slower (0.431 vs 0.268+0.085 ms)
+int g_sap8 = 1;             // TD_SAP8          lean u8 finisher
+int g_psap8_batches = 1;    // TD_PSAP8         speculative batches of the lean u8 search
+int g_psap8_grid = 64;      // TD_PSAP8_GRID    searches per such batch
+int g_psap_batches = 16;    // TD_PSAP          max speculative batches of the generic search (u16 / u32 rows)
+int g_psap_min = 12;        // TD_PSAP_MIN      free rows below which the generic batches are skipped
+int g_psap_u8 = 0;          // TD_PSAP_U8       generic batches for u8 rows too (slower than the lean path)
+int g_onewave = 0;          // TD_ONEWAVE       single-wavefront generic finisher for small models (no gain)
+int g_solver_eps = 0;       // TD_SOLVER=eps    literal eps-scaling auction (comparison mode)
+int g_eps_theta = 8;        // TD_EPS_THETA
+long long g_eps0_mult = 4;  // TD_EPS0_MULT     eps0 = (n+1) * mult ; 0 = start at eps = 1
 void read_tunables()
 {
     static bool done = false;
