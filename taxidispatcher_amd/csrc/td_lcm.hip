@@ -236,6 +236,266 @@ __global__ __launch_bounds__(1024) void k_lcm_loop(int n, const int32_t *__restr
     }
 }
 
+// =====================================================================================
+// Level-list LCM (the fast path of td_lcm).
+//
+// When the candidate values span < LV_MAX levels — true for every reference variant: distances
+// up to the threshold (greedy_opt.py: 0..10, simulate.py: 0..20), stand distances below
+// DROP_TIME (Simulator.java: 0..9), heuristic.py costs 1..39 — the greedy is done on explicit
+// cell lists instead of row re-scans:
+//   k_lcms_minmax   one streaming read: min / max / count of the candidate cells
+//   k_lcms_hist     one read: per row and level the number of candidates
+//   k_lcms_scan     exclusive scan (level-major, then row) -> list offsets
+//   k_lcms_scatter  one read: cells written as (row<<16 | col) into their level list, row-major
+//                   inside a level  ==> the lists, concatenated, are the matrix sorted by the
+//                   reference's key (value, row, col)
+//   k_lcms_greedy   one workgroup walks the lists 1024 cells at a time: a live cell (row and
+//                   column still free) is taken iff no EARLIER live cell of the chunk shares its
+//                   row or column (LDS atomicMin per row / column), repeated until the chunk has
+//                   no live cell; survivors are exactly the cells the sequential greedy takes,
+//                   and they are emitted in list order.
+// =====================================================================================
+constexpr int LV_MAX = 64;
+static int g_lcm_lists = getenv("TD_LCM_LISTS") ? atoi(getenv("TD_LCM_LISTS")) : 1;   // 0: always the row-scan loop
+
+struct LcmsInfo {
+    long long count;   // candidate cells
+    int vmin, vmax;
+    int pad[2];
+};
+
+__global__ __launch_bounds__(256) void k_lcms_minmax(int n, const int32_t *__restrict__ cost, int64_t hi,
+                                                     LcmsInfo *__restrict__ info)
+{
+    int mn = INT_MAX, mx = INT_MIN;
+    long long cnt = 0;
+    const int64_t total = (int64_t)n * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = cost[i];
+        if ((int64_t)v <= hi) {
+            mn = min(mn, v);
+            mx = max(mx, v);
+            cnt++;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o));
+        mx = max(mx, __shfl_xor(mx, o));
+        cnt += __shfl_xor(cnt, o);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        atomicMin(&info->vmin, mn);
+        atomicMax(&info->vmax, mx);
+        atomicAdd((unsigned long long *)&info->count, (unsigned long long)cnt);
+    }
+}
+
+// one wavefront per row; SCATTER = false: count per level, true: write the cells
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_lcms_rows(int n, const int32_t *__restrict__ cost, int64_t hi, int vmin, int nlev,
+                                                   int *__restrict__ rowcnt /* [nlev][n] counts, then offsets */,
+                                                   uint32_t *__restrict__ cells)
+{
+    __shared__ int s_cnt[4][LV_MAX];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int row = blockIdx.x * nw + w; row < n; row += gridDim.x * nw) {
+        for (int l = lane; l < nlev; l += 64) s_cnt[w][l] = SCATTER ? rowcnt[(size_t)l * n + row] : 0;
+        const int32_t *rp = cost + (int64_t)row * n;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            const int v = (j < n) ? rp[j] : 0;
+            int lv = (j < n && (int64_t)v <= hi) ? v - vmin : -1;
+            unsigned long long act = __ballot(lv >= 0);
+            while (act) {
+                // lowest level present among the still-active lanes (wave-uniform)
+                int cur = lv >= 0 ? lv : INT_MAX;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) cur = min(cur, __shfl_xor(cur, o));
+                const unsigned long long m = __ballot(lv == cur);
+                if (SCATTER) {
+                    const int base = s_cnt[w][cur];
+                    if (lv == cur) cells[base + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)row << 16) | (uint32_t)j;
+                }
+                if (lane == 0) s_cnt[w][cur] += __popcll(m);
+                if (lv == cur) lv = -1;
+                act &= ~m;
+            }
+        }
+        if (!SCATTER)
+            for (int l = lane; l < nlev; l += 64) rowcnt[(size_t)l * n + row] = s_cnt[w][l];
+    }
+}
+
+// exclusive scan of rowcnt[nlev*n] in place (one workgroup), level starts to lvstart[nlev+1]
+__global__ __launch_bounds__(1024) void k_lcms_scan(int total, int n, int nlev, int *__restrict__ a, int *__restrict__ lvstart)
+{
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < total; base += 1024) {
+        const int i = base + tid;
+        const int v = i < total ? a[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_w[w] = incl;
+        __syncthreads();
+        int wb = 0;
+        for (int k = 0; k < w; k++) wb += s_w[k];
+        const int carry = s_carry;
+        const int excl = carry + wb + incl - v;
+        if (i < total) {
+            a[i] = excl;
+            if (i % n == 0) lvstart[i / n] = excl;
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + wb + incl;
+        __syncthreads();
+    }
+    if (tid == 0) lvstart[nlev] = s_carry;
+}
+
+__global__ __launch_bounds__(1024) void k_lcms_greedy(int n, int hmask, int nlev, int vmin,
+                                                      const uint32_t *__restrict__ cells,
+                                                      const int *__restrict__ lvstart, int limit, int64_t sum_below,
+                                                      int32_t stop_value, int32_t *__restrict__ rows,
+                                                      int32_t *__restrict__ cols, LcmOut *__restrict__ out,
+                                                      int *__restrict__ exhausted, uint32_t *__restrict__ g_taken)
+{
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    // [row table: hmask+1 ints][column table: hmask+1 ints][rows taken: bits][columns taken: bits]
+    // The tables are indexed by (row & hmask) / (col & hmask): when n exceeds the table two rows can
+    // share a slot, which only delays the later cell to the next pass (the test stays sufficient).
+    int *rmin = reinterpret_cast<int *>(s_dyn);
+    int *cmin = rmin + (hmask + 1);
+    const int nw32 = (n + 31) / 32;
+    uint32_t *rtk = reinterpret_cast<uint32_t *>(cmin + (hmask + 1));
+    uint32_t *ctk = rtk + nw32;
+    __shared__ int s_w[16];
+    __shared__ int s_any;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i <= hmask; i += 1024) {
+        rmin[i] = INT_MAX;
+        cmin[i] = INT_MAX;
+    }
+    for (int i = tid; i < nw32; i += 1024) {
+        rtk[i] = 0u;
+        ctk[i] = 0u;
+    }
+    __syncthreads();
+    int npairs = 0;
+    int64_t total = 0;
+    int32_t last_min = stop_value;
+    bool done = (limit <= 0);
+    for (int lv = 0; lv < nlev && !done; lv++) {
+        const int32_t val = vmin + lv;
+        const int beg = lvstart[lv], end = lvstart[lv + 1];
+        for (int base = beg; base < end && !done; base += 1024) {
+            const int i = base + tid;
+            int r = 0, c = 0;
+            bool live = false;
+            if (i < end) {
+                const uint32_t rc = cells[i];
+                r = (int)(rc >> 16);
+                c = (int)(rc & 0xFFFFu);
+                live = !((rtk[r >> 5] >> (r & 31)) & 1u) && !((ctk[c >> 5] >> (c & 31)) & 1u);
+            }
+            const int hr = r & hmask, hc = c & hmask;
+            bool taken = false;
+            for (int pass = 0; pass < 1024; pass++) {
+                if (tid == 0) s_any = 0;
+                __syncthreads();
+                if (live) {
+                    atomicMin(&rmin[hr], tid);
+                    atomicMin(&cmin[hc], tid);
+                    s_any = 1;
+                }
+                __syncthreads();
+                if (!s_any) break;
+                const bool win = live && rmin[hr] == tid && cmin[hc] == tid;
+                __syncthreads();
+                if (live) {   // reset only what was touched
+                    rmin[hr] = INT_MAX;
+                    cmin[hc] = INT_MAX;
+                }
+                if (win) {
+                    atomicOr(&rtk[r >> 5], 1u << (r & 31));
+                    atomicOr(&ctk[c >> 5], 1u << (c & 31));
+                    taken = true;
+                    live = false;
+                }
+                __syncthreads();
+                if (live) live = !((rtk[r >> 5] >> (r & 31)) & 1u) && !((ctk[c >> 5] >> (c & 31)) & 1u);
+            }
+            // emit the taken cells of this chunk in list order
+            const unsigned long long m = __ballot(taken);
+            if (lane == 0) s_w[w] = __popcll(m);
+            __syncthreads();
+            int wb = 0, tot = 0;
+            for (int k = 0; k < 16; k++) {
+                wb += (k < w) ? s_w[k] : 0;
+                tot += s_w[k];
+            }
+            const int pos = npairs + wb + __popcll(m & ((1ull << lane) - 1ull));
+            if (taken && pos < limit) {
+                rows[pos] = r;
+                cols[pos] = c;
+            }
+            const int acc = min(tot, limit - npairs);
+            if (acc > 0) {
+                last_min = val;
+                if ((int64_t)val < sum_below) total += (int64_t)val * acc;
+            }
+            npairs += acc;
+            if (npairs >= limit) done = true;
+            __syncthreads();
+        }
+    }
+    // Lists exhausted before the size limit: the reference's next look at the matrix decides
+    // last_min (k_lcms_lastmin), it needs to know which rows / columns are gone.
+    if (!done) {
+        for (int i = tid; i < nw32; i += 1024) {
+            g_taken[i] = rtk[i];
+            g_taken[nw32 + i] = ctk[i];
+        }
+    }
+    if (tid == 0) {
+        *exhausted = done ? 0 : 1;
+        out->n_pairs = npairs;
+        out->last_min = done ? last_min : INT_MAX;
+        out->total = total;
+    }
+}
+
+// after exhausted lists: smallest cell (below cand_limit) among the rows / columns still free
+__global__ __launch_bounds__(256) void k_lcms_lastmin(int n, const int32_t *__restrict__ cost, int64_t cand_limit,
+                                                      const int *__restrict__ exhausted,
+                                                      const uint32_t *__restrict__ g_taken, LcmOut *__restrict__ out)
+{
+    if (!*exhausted) return;
+    const int nw32 = (n + 31) / 32;
+    const uint32_t *rtk = g_taken, *ctk = g_taken + nw32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int mn = INT_MAX;
+    for (int row = blockIdx.x * nw + w; row < n; row += gridDim.x * nw) {
+        if ((rtk[row >> 5] >> (row & 31)) & 1u) continue;
+        const int32_t *rp = cost + (int64_t)row * n;
+        for (int j = lane; j < n; j += 64) {
+            const int v = rp[j];
+            if (!((ctk[j >> 5] >> (j & 31)) & 1u) && (int64_t)v < cand_limit) mn = min(mn, v);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
+    if (lane == 0 && mn != INT_MAX) atomicMin(&out->last_min, mn);
+}
+
 }  // namespace
 
 extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshold, int stop_value_on,
@@ -267,7 +527,56 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
     // Java's scan only ever sees cells strictly below big_cost (Simulator.java:529-537)
     const int64_t cand_limit = stop_value_on ? (int64_t)stop_value : (int64_t)INT64_MAX;
     const size_t shm_mask = sizeof(uint32_t) * (size_t)((n + 31) / 32);
-    {
+    bool fast = false;
+    if (g_lcm_lists && n >= 64 && n <= 65536) {
+        // level lists: candidates are the cells the loop could ever take
+        int64_t hi = std::min<int64_t>(cand_limit - 1, (int64_t)mask - 1);
+        if (threshold >= 0) hi = std::min<int64_t>(hi, threshold);
+        LcmsInfo *d_info = (LcmsInfo *)((char *)c.lcm_d.p + 64);
+        LcmsInfo init;
+        init.count = 0;
+        init.vmin = INT_MAX;
+        init.vmax = INT_MIN;
+        init.pad[0] = init.pad[1] = 0;
+        LcmsInfo info;
+        {
+            ProfScope ps(TD_K_LCM);
+            TD_HIP(hipMemcpyAsync(d_info, &init, sizeof(init), hipMemcpyHostToDevice, c.stream));
+            const int64_t cellsN = (int64_t)n * n;
+            const int grid = (int)std::min<int64_t>((cellsN + 1023) / 1024, (int64_t)c.n_cu * 8);
+            k_lcms_minmax<<<grid, 256, 0, c.stream>>>(n, d_cost, hi, d_info);
+        }
+        TD_HIP(hipMemcpyAsync(c.pinned, d_info, sizeof(LcmsInfo), hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipStreamSynchronize(c.stream));
+        info = *(const LcmsInfo *)c.pinned;
+        if (info.count > 0 && info.count <= (1ll << 28) && (int64_t)info.vmax - info.vmin < LV_MAX) {
+            fast = true;
+            const int nlev = info.vmax - info.vmin + 1;
+            const int nw32 = (n + 31) / 32;
+            if ((rc = ensure(c.lcm_a, sizeof(int) * (size_t)nlev * n))) return rc;
+            if ((rc = ensure(c.cc, sizeof(uint32_t) * (size_t)info.count))) return rc;
+            if ((rc = ensure(c.lcm_c, sizeof(int) * (LV_MAX + 2) + sizeof(uint32_t) * 2 * (size_t)nw32 + 64))) return rc;
+            int *d_cnt = (int *)c.lcm_a.p;
+            int *d_lvstart = (int *)c.lcm_c.p;
+            uint32_t *d_taken = (uint32_t *)(d_lvstart + LV_MAX + 2);
+            int *d_exh = (int *)((char *)c.lcm_d.p + 96);
+            int hsz = 64;
+            while (hsz < n && hsz < 16384) hsz <<= 1;
+            const int limit = (stop_size >= 0 && stop_size < n) ? std::min(cap, n - stop_size) : cap;
+            const size_t shm = sizeof(int) * 2 * (size_t)hsz + sizeof(uint32_t) * 2 * (size_t)nw32;
+            ProfScope ps(TD_K_LCM);
+            const int rgrid = std::min((n + 3) / 4, c.n_cu * 8);
+            k_lcms_rows<false><<<rgrid, 256, 0, c.stream>>>(n, d_cost, hi, info.vmin, nlev, d_cnt, nullptr);
+            k_lcms_scan<<<1, 1024, 0, c.stream>>>(nlev * n, n, nlev, d_cnt, d_lvstart);
+            k_lcms_rows<true><<<rgrid, 256, 0, c.stream>>>(n, d_cost, hi, info.vmin, nlev, d_cnt, (uint32_t *)c.cc.p);
+            if (shm > 48 * 1024)
+                (void)hipFuncSetAttribute((const void *)k_lcms_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            k_lcms_greedy<<<1, 1024, shm, c.stream>>>(n, hsz - 1, nlev, info.vmin, (const uint32_t *)c.cc.p, d_lvstart, limit,
+                                                      sum_below, stop_value, d_rows, d_cols, (LcmOut *)c.lcm_d.p, d_exh, d_taken);
+            k_lcms_lastmin<<<rgrid, 256, 0, c.stream>>>(n, d_cost, cand_limit, d_exh, d_taken, (LcmOut *)c.lcm_d.p);
+        }
+    }
+    if (!fast) {
         ProfScope ps(TD_K_LCM);
         TD_HIP(hipMemsetD32Async((hipDeviceptr_t)d_base, INT_MAX, 1, c.stream));
         k_lcm_rowscan<<<std::min((n + 3) / 4, c.n_cu * 8), 256, 0, c.stream>>>(n, d_cost, cand_limit,
@@ -287,7 +596,8 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
     TD_HIP(hipGetLastError());
     TD_HIP(hipMemcpyAsync(c.pinned, c.lcm_d.p, sizeof(LcmOut), hipMemcpyDeviceToHost, c.stream));
     TD_HIP(hipStreamSynchronize(c.stream));
-    const LcmOut o = *(const LcmOut *)c.pinned;
+    LcmOut o = *(const LcmOut *)c.pinned;
+    if (fast && o.last_min == INT_MAX) o.last_min = stop_value_on ? stop_value : mask;   // nothing left to look at
     if (o.n_pairs > 0) {
         const hipMemcpyKind kr = is_device_ptr(rows) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
         const hipMemcpyKind kc = is_device_ptr(cols) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;

@@ -158,7 +158,7 @@ def solve(distances, demand, cabs, big_cost=BIG_COST, drop_time=None):
     return n, expand_x(n, r2c), cost
 
 
-def _lcm(n, c, mask, threshold, stop_value_on, stop_value, stop_size, sum_below):
+def _lcm(n, c, mask, threshold, stop_value_on, stop_value, stop_size, sum_below, max_pairs=None):
     lib = _ffi.lib()
     if not hasattr(c, "data_ptr"):
         c = _ffi.as_i32(c).reshape(n, n)
@@ -168,7 +168,7 @@ def _lcm(n, c, mask, threshold, stop_value_on, stop_value, stop_size, sum_below)
     tot = ctypes.c_int64(0)
     lm = ctypes.c_int32(0)
     _ffi.check(lib.td_lcm(n, _ffi.addr(c), int(mask), int(threshold), int(stop_value_on), int(stop_value),
-                          int(stop_size), int(sum_below), n, _ffi.addr(rows), _ffi.addr(cols), ctypes.byref(k),
+                          int(stop_size), int(sum_below), n if max_pairs is None else int(max_pairs), _ffi.addr(rows), _ffi.addr(cols), ctypes.byref(k),
                           ctypes.byref(tot), ctypes.byref(lm)))
     return int(tot.value), rows[:k.value].copy(), cols[:k.value].copy(), int(lm.value)
 

@@ -201,6 +201,79 @@ def test_reference_shaped_calculate_cost_and_solve(td):
     assert td.solve(dist, [], [], drop_time=10) == (0, [], 0)
 
 
+def test_lcm_randomized_differential(td):
+    """td_lcm against the oracle over random shapes of every stop rule: threshold, stop value,
+    stop size, pair cap, masked cells, exhausted lists; instances with few value levels take the
+    level-list kernels, wide ones the row-scan loop - all five outputs must agree."""
+    from taxidispatcher_amd import dispatch
+    rng = np.random.default_rng(20260)
+    for trial in range(160):
+        n = int(rng.choice([1, 2, 5, 63, 64, 65, 100, 129, 257, 400, 1000]))
+        kind = trial % 4
+        if kind == 0:      # distances 0..R with masked cells, thresholded (greedy_opt.py / simulate.py)
+            R = int(rng.choice([3, 15, 40, 200]))
+            c = rng.integers(0, R + 1, (n, n)).astype(np.int32)
+            c[rng.random((n, n)) < rng.choice([0.0, 0.3, 0.9])] = BIG
+            args = dict(mask=BIG, threshold=int(rng.choice([0, 2, 10, 20])), sum_below=BIG)
+        elif kind == 1:    # Simulator.java: stop value = big cost, stop at a model size
+            c = rng.integers(0, 10, (n, n)).astype(np.int32)
+            c[rng.random((n, n)) < rng.choice([0.2, 0.8, 0.97])] = BIG
+            args = dict(mask=BIG, stop_value_on=1, stop_value=BIG, stop_size=int(rng.choice([-1, 0, n // 3, n - 1, n, n + 5])),
+                        sum_below=BIG)
+        elif kind == 2:    # heuristic.py: every cell a candidate, small mask value
+            c = rng.integers(1, 40, (n, n)).astype(np.int32)
+            args = dict(mask=100, threshold=-1)
+        else:              # wide values, negative values, pair cap
+            lo = int(rng.choice([-50, 0]))
+            c = rng.integers(lo, lo + int(rng.choice([30, 60, 100000])), (n, n)).astype(np.int32)
+            args = dict(mask=BIG, threshold=int(rng.choice([-1, 25])), sum_below=int(rng.choice([BIG, 20])),
+                        max_iter=int(rng.integers(0, n + 1)))
+        t_o, r_o, c_o, lm_o = oracle.lcm(c, **args)
+        got = dispatch._lcm(n, c, args["mask"], args.get("threshold", -1), args.get("stop_value_on", 0),
+                            args.get("stop_value", 0), args.get("stop_size", -1), args.get("sum_below", 2**62),
+                            max_pairs=args.get("max_iter"))
+        assert (got[0], got[3]) == (t_o, lm_o), (trial, n, args, got[0], t_o, got[3], lm_o)
+        assert np.array_equal(got[1], r_o) and np.array_equal(got[2], c_o), (trial, n, args)
+
+
+def _sorted_cell_greedy(c, threshold):
+    """Test-local restatement of the thresholded lowest-cost method for SPARSE candidates:
+    cells at or below the threshold in (value, row, col) order, taken when row and column are
+    free (what repeated np.argmin + masking does, greedy_opt.py:61-82). The oracle's O(n^2) scan
+    per pick is too slow at n = 20000; this one is checked against it at small n below."""
+    n = c.shape[0]
+    r, k = np.nonzero(c <= threshold)
+    v = c[r, k]
+    order = np.lexsort((k, r, v))
+    rt, ct = np.zeros(n, bool), np.zeros(n, bool)
+    rows, cols, tot = [], [], 0
+    for i in order:
+        a, b = r[i], k[i]
+        if not rt[a] and not ct[b]:
+            rt[a] = ct[b] = True
+            rows.append(a)
+            cols.append(b)
+            tot += int(v[i])
+    return tot, np.array(rows, np.int32), np.array(cols, np.int32)
+
+
+def test_lcm_large_hashed_tables(td):
+    """n above 16384: the row / column tables of the list greedy are shared by several rows."""
+    from taxidispatcher_amd import dispatch
+    for n, per_row in ((300, 6), (20000, 40)):
+        rng = np.random.default_rng(5)
+        c = np.full((n, n), BIG, np.int32)
+        k = per_row * n
+        c[rng.integers(0, n, k), rng.integers(0, n, k)] = rng.integers(0, 12, k).astype(np.int32)
+        t_o, r_o, c_o = _sorted_cell_greedy(c, 10)
+        if n <= 300:
+            t_x, r_x, c_x, _ = oracle.lcm(c, mask=BIG, threshold=10, sum_below=BIG)
+            assert t_x == t_o and np.array_equal(r_x, r_o) and np.array_equal(c_x, c_o)
+        got = dispatch._lcm(n, c, BIG, 10, 0, 0, -1, BIG)
+        assert got[0] == t_o
+        assert np.array_equal(got[1], r_o) and np.array_equal(got[2], c_o)
+
+
 @pytest.mark.parametrize("n", [1, 5, 17, 64, 100, 400, 1300])
 def test_lcm_variants(td, n):
     rng = np.random.default_rng(77 + n)
