@@ -75,11 +75,15 @@ enum {
     CTL_ERR = 1,       // device-side consistency error
     CTL_NFREE = 2,     // rows handed to SAP
     CTL_STEPS = 3,     // SAP dijkstra steps
-    CTL_ROUNDS = 4,    // bidding rounds that placed at least one bid
+    CTL_NCONST = 4,    // constant rows seen by the compress pass (survives k_init_state)
     CTL_PACC = 5,      // augmentations committed by the parallel finisher
     CTL_RANGE = 6,     // [6..7] 64-bit max row range seen by a compress pass that did not fit
     CTL_PROG = 8,      // [CTL_PROG + r] bids applied in round r
-    CTL_WORDS = 8 + 64  // room for up to 48 rounds
+    CTL_WORDS = 8 + 64,  // room for up to 48 rounds
+    // shape probe (k_shape): [+0] constant-looking columns, [+1] rows, [+2] block ticket,
+    // [+3] 1 = solve the transpose, [+4..5] 64-bit largest sampled column range
+    CTL_SHAPE = CTL_WORDS,
+    CTL_ALL = CTL_WORDS + 8
 };
 
 constexpr int ROW_BITS = 20;
@@ -102,6 +106,9 @@ int g_psap_batches = 16;    // TD_PSAP          max speculative batches of the g
 int g_psap_min = 12;        // TD_PSAP_MIN      free rows below which the generic batches are skipped
 int g_psap_u8 = 0;          // TD_PSAP_U8       generic batches for u8 rows too (slower than the lean path)
 int g_onewave = 0;          // TD_ONEWAVE       single-wavefront generic finisher for small models (no gain)
+int g_defer_const = 1;      // TD_DEFER_CONST   constant rows sit out the solve (k_place_const)
+int g_shape = 1;            // TD_SHAPE         probe for constant columns and solve the transpose when they dominate
+int g_shape_max_n = 1 << 20; // TD_SHAPE_MAX_N   largest n the probe runs for
 int g_solver_eps = 0;       // TD_SOLVER=eps    literal eps-scaling auction (comparison mode)
 int g_eps_theta = 8;        // TD_EPS_THETA
 long long g_eps0_mult = 4;  // TD_EPS0_MULT     eps0 = (n+1) * mult ; 0 = start at eps = 1
@@ -128,6 +135,9 @@ void read_tunables()
     if (const char *e = getenv("TD_EPS_THETA")) g_eps_theta = std::max(2, atoi(e));
     if (const char *e = getenv("TD_ONEWAVE")) g_onewave = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("TD_PSAP8")) g_psap8_batches = std::max(0, std::min(32, atoi(e)));
+    if (const char *e = getenv("TD_DEFER_CONST")) g_defer_const = atoi(e) != 0;
+    if (const char *e = getenv("TD_SHAPE")) g_shape = atoi(e) != 0;
+    if (const char *e = getenv("TD_SHAPE_MAX_N")) g_shape_max_n = atoi(e);
     if (const char *e = getenv("TD_PSAP8_GRID")) g_psap8_grid = std::max(1, std::min(192, atoi(e)));
 }
 
@@ -189,7 +199,7 @@ __device__ __forceinline__ T shfl_xor_t(T v, int m)
 template <typename CT, bool VEC>
 __global__ __launch_bounds__(256) void k_compress(int n, int nrows, int nchunks, const int32_t *__restrict__ cost,
                                                   CT *__restrict__ cc, int32_t *__restrict__ rowmin,
-                                                  int *__restrict__ ctl)
+                                                  int *__restrict__ ctl, int *__restrict__ rconst)
 {
     constexpr int E = Tr<CT>::E;
     __shared__ int s_mn[4], s_mx[4];
@@ -227,6 +237,8 @@ __global__ __launch_bounds__(256) void k_compress(int n, int nrows, int nchunks,
         __syncthreads();
         if (tid == 0) {
             rowmin[row] = mn;
+            rconst[row] = (mx == mn) ? 1 : 0;   // a constant row can take ANY column at the same cost
+            if (mx == mn) atomicAdd(&ctl[CTL_NCONST], 1);
             if ((int64_t)mx - (int64_t)mn > Tr<CT>::LIMIT) {
                 atomicOr(&ctl[CTL_FLAG], 1);
                 atomicMax(reinterpret_cast<unsigned long long *>(&ctl[CTL_RANGE]), (unsigned long long)((int64_t)mx - (int64_t)mn));
@@ -283,8 +295,8 @@ __global__ __launch_bounds__(256) void k_compress(int n, int nrows, int nchunks,
 template <typename CT, int VPT, int THREADS, bool BID0 = false>
 __global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nrows, int nchunks, const int32_t *__restrict__ cost,
                                                           CT *__restrict__ cc, int32_t *__restrict__ rowmin,
-                                                          int *__restrict__ ctl, unsigned long long *__restrict__ bid = nullptr,
-                                                          int row0 = 0)
+                                                          int *__restrict__ ctl, int *__restrict__ rconst,
+                                                          unsigned long long *__restrict__ bid = nullptr, int row0 = 0)
 {
     constexpr int E = Tr<CT>::E;
     constexpr int NW = THREADS / 64;
@@ -338,6 +350,8 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nrows, int 
         par ^= 1;
         if (tid == 0) {
             rowmin[row] = mn;
+            rconst[row] = (mx == mn) ? 1 : 0;   // a constant row can take ANY column at the same cost
+            if (mx == mn) atomicAdd(&ctl[CTL_NCONST], 1);
             if ((int64_t)mx - (int64_t)mn > Tr<CT>::LIMIT) {
                 atomicOr(&ctl[CTL_FLAG], 1);
                 atomicMax(reinterpret_cast<unsigned long long *>(&ctl[CTL_RANGE]), (unsigned long long)((int64_t)mx - (int64_t)mn));
@@ -440,7 +454,7 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nrows, int 
 // =====================================================================================
 template <typename PT>
 __global__ void k_init_state(int n, int npad, int nrows, PT *pk, PT padkey, int *owner, int *r2c,
-                             unsigned long long *bid, int *ctl)
+                             unsigned long long *bid, int *ctl, const int *rconst)
 {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < npad) {
@@ -448,8 +462,9 @@ __global__ void k_init_state(int n, int npad, int nrows, PT *pk, PT padkey, int 
         bid[j] = 0ull;
         owner[j] = (j < n) ? -1 : -2;
     }
-    if (j < nrows) r2c[j] = -1;
-    if (j < CTL_WORDS && j != CTL_FLAG && j != CTL_RANGE && j != CTL_RANGE + 1) ctl[j] = 0;
+    // -1: free row; -2: constant row, deferred to k_place_const (never bids, never searched)
+    if (j < nrows) r2c[j] = (rconst && rconst[j]) ? -2 : -1;
+    if (j < CTL_WORDS && j != CTL_FLAG && j != CTL_NCONST && j != CTL_RANGE && j != CTL_RANGE + 1) ctl[j] = 0;
 }
 
 // =====================================================================================
@@ -483,7 +498,7 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nrows, int
         P = sp;
     }
     for (int lrow = blockIdx.x * nw + w; lrow < nrows; lrow += gridDim.x * nw) {
-        if (r2c[lrow] >= 0) continue;
+        if (r2c[lrow] != -1) continue;   // assigned, or a deferred constant row
         const int row = row0 + lrow;  // global row id (shards own rows [row0, row0+nrows))
         const CT *rp = cc + (size_t)lrow * pitch;
         // Start chunk of the rotated scan.  It spreads the tie-breaks of different rows over the
@@ -605,7 +620,7 @@ __global__ __launch_bounds__(256) void k_bid_row(int n, int nrows, int row0, int
     if (ctl[CTL_FLAG]) return;
     if (round > 0 && ctl[CTL_PROG + round - 1] == 0) return;
     const int lrow = blockIdx.x;
-    if (lrow >= nrows || r2c[lrow] >= 0) return;
+    if (lrow >= nrows || r2c[lrow] != -1) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const size_t pitch = (size_t)nchunks * E;
     const int row = row0 + lrow;
@@ -727,10 +742,10 @@ __global__ __launch_bounds__(256) void k_assign(int n, int nrows, int row0, unsi
     }
 }
 
-// Ordered list of the free rows (r2c < 0), built by ONE workgroup: every thread counts the free
+// Ordered list of the entries equal to `want` (free rows: r2c == -1), built by ONE workgroup: every thread counts the free
 // rows of its own contiguous slice, one block-wide exclusive scan (wave DPP-free shuffle scan +
 // 16-entry LDS exchange), then every thread writes its rows at its offset.  Returns the count.
-__device__ __forceinline__ int build_free_list(int n, const int *__restrict__ r2c, int *__restrict__ list)
+__device__ __forceinline__ int build_free_list(int n, const int *__restrict__ r2c, int *__restrict__ list, int want = -1)
 {
     __shared__ int s_fl_w[16];
     __shared__ int s_fl_tot;
@@ -738,7 +753,7 @@ __device__ __forceinline__ int build_free_list(int n, const int *__restrict__ r2
     const int per = (n + T - 1) / T;
     const int lo = tid * per, hi = min(n, lo + per);
     int cnt = 0;
-    for (int r = lo; r < hi; r++) cnt += (r2c[r] < 0) ? 1 : 0;
+    for (int r = lo; r < hi; r++) cnt += (r2c[r] == want) ? 1 : 0;
     int incl = cnt;  // inclusive scan within the wave
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -752,9 +767,11 @@ __device__ __forceinline__ int build_free_list(int n, const int *__restrict__ r2
     if (tid == T - 1) s_fl_tot = base + incl;
     int pos = base + incl - cnt;
     for (int r = lo; r < hi; r++)
-        if (r2c[r] < 0) list[pos++] = r;
+        if (r2c[r] == want) list[pos++] = r;
     __syncthreads();
-    return s_fl_tot;
+    const int tot = s_fl_tot;
+    __syncthreads();   // the scratch is reused by a second call
+    return tot;
 }
 
 __global__ __launch_bounds__(1024) void k_freelist(int n, const int *__restrict__ r2c, int *__restrict__ list,
@@ -763,6 +780,103 @@ __global__ __launch_bounds__(1024) void k_freelist(int n, const int *__restrict_
     if (ctl[CTL_FLAG]) return;
     const int cnt = build_free_list(n, r2c, list);
     if (threadIdx.x == 0) ctl[CTL_NFREE] = cnt;
+}
+
+// Constant rows (every cell equal: dummy rows of a padded rectangular model, cabs with no request
+// in range) cost the same in any column, so they sit out the bidding and the searches and take
+// the columns nobody owns at the end, k-th constant row <- k-th free column. Exactness: a column
+// that was never owned still has price 0 and prices never go below 0, so the row's dual
+// min_j(c + p_j) is attained there and the LP certificate (k_dual) closes as before.
+__global__ __launch_bounds__(1024) void k_place_const(int n, int *__restrict__ r2c, int *__restrict__ owner,
+                                                      int *__restrict__ lista, int *__restrict__ listb,
+                                                      int *__restrict__ ctl)
+{
+    if (ctl[CTL_FLAG] || ctl[CTL_NCONST] == 0) return;
+    const int nr = build_free_list(n, r2c, lista, -2);
+    if (nr == 0) return;
+    const int nc = build_free_list(n, owner, listb, -1);
+    if (nc != nr) {   // free rows left by the finisher, or a broken owner table
+        if (threadIdx.x == 0) atomicOr(&ctl[CTL_ERR], 8);
+        return;
+    }
+    for (int k = threadIdx.x; k < nr; k += blockDim.x) {
+        const int r = lista[k], j = listb[k];
+        r2c[r] = j;
+        owner[j] = r;
+    }
+}
+
+// Shape probe (td_assign, speculative attempt only, right after the compress pass): 16 sampled
+// rows estimate how many COLUMNS are constant; the compress pass has counted the constant rows
+// exactly. Many constant columns (dummy requests of a padded rectangular model,
+// Simulator.java:244-252) mean the row-wise solve would have to price hundreds of rows out of the
+// real columns, a price war of ~big_cost / (cost step) rounds; the transposed problem has them as
+// constant ROWS, which are deferred. Sets CTL_FLAG bit 2 -> every later kernel of the attempt
+// exits, the host transposes and redoes. The probe only picks the cheaper of two exact
+// formulations; its estimate needs no guarantee.
+__global__ __launch_bounds__(256) void k_shape(int n, const int32_t *__restrict__ cost, int *__restrict__ ctl)
+{
+    int *sh = ctl + CTL_SHAPE;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int cc = 0;
+    long long rng = 0;
+    if (t < n) {   // column t over 16 sampled rows: coalesced
+        const int v0 = cost[t];
+        int mn = v0, mx = v0;
+#pragma unroll
+        for (int k = 1; k < 16; k++) {
+            const int v = cost[(int64_t)(((int64_t)k * n) >> 4) * n + t];
+            mn = min(mn, v);
+            mx = max(mx, v);
+        }
+        cc = (mn == mx) ? 1 : 0;
+        rng = (long long)mx - (long long)mn;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cc += __shfl_xor(cc, o);
+        const long long orng = __shfl_xor(rng, o);
+        rng = orng > rng ? orng : rng;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cc) atomicAdd(&sh[0], cc);
+        // lower bound of the transposed problem's row range: lets the redo skip widths that cannot fit
+        if (rng > 254) atomicMax(reinterpret_cast<unsigned long long *>(&sh[4]), (unsigned long long)rng);
+    }
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = (atomicAdd(&sh[2], 1) == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        __threadfence();
+        const int ncol = atomicAdd(&sh[0], 0);
+        const int nrow = ctl[CTL_NCONST];
+        sh[1] = nrow;
+        if (ncol >= 16 && ncol * 16 >= n && ncol > 2 * nrow) {
+            sh[3] = 1;
+            atomicOr(&ctl[CTL_FLAG], 4);
+        }
+    }
+}
+
+// out[j][i] = in[i][j], 64 x 64 tiles through LDS (both sides coalesced)
+__global__ __launch_bounds__(256) void k_transpose(int n, const int32_t *__restrict__ in, int32_t *__restrict__ out)
+{
+    __shared__ int32_t tile[64][65];
+    const int bx = blockIdx.x * 64, by = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int i = by + r, j = bx + tx;
+        if (i < n && j < n) tile[r][tx] = in[(int64_t)i * n + j];
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int j = bx + r, i = by + tx;
+        if (i < n && j < n) out[(int64_t)j * n + i] = tile[tx][r];
+    }
 }
 
 // =====================================================================================
@@ -1829,10 +1943,11 @@ struct td_shard {
     bool fused_bid0 = false;  // the compress pass already published bidding round 0
     int nchunks = 0, npad = 0;
     const int32_t *d_cost = nullptr;  // nrows x n, device
-    Buf stage, cc, price, owner, r2c, r2c_full, bid, pred, list, rowmin, misc, psrec;
+    Buf stage, cc, price, owner, r2c, r2c_full, bid, pred, list, rowmin, rconst, misc, psrec, tbuf;
+    bool defer_const = false;  // constant rows sit out the solve and take the left-over columns (td_assign only)
     void free_all()
     {
-        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &misc, &psrec};
+        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &rconst, &misc, &psrec, &tbuf};
         for (Buf *b : bs) {
             if (b->p) (void)hipFree(b->p);
             b->p = nullptr;
@@ -1860,6 +1975,7 @@ int sv_prepare(Solver &sv, int n, int row0, int nrows, const int32_t *cost)
     const size_t np = (size_t)((n + 3) / 4) * 4 + 16;
     if ((rc = ensure(sv.misc, 4096))) return rc;
     if ((rc = ensure(sv.rowmin, sizeof(int32_t) * (size_t)std::max(nrows, 1)))) return rc;
+    if ((rc = ensure(sv.rconst, sizeof(int) * (size_t)std::max(nrows, 1)))) return rc;
     if ((rc = ensure(sv.price, sizeof(int64_t) * np))) return rc;
     if ((rc = ensure(sv.owner, sizeof(int) * np))) return rc;
     if ((rc = ensure(sv.r2c, sizeof(int) * np))) return rc;
@@ -1880,7 +1996,7 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false, bool bid0 = fa
     int rc;
     if ((rc = ensure(sv.cc, std::max<size_t>((size_t)nrows * nchunks * 16, 256)))) return rc;
     int *ctl = (int *)sv.misc.p;
-    TD_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(int), c.stream));  // flag, error, stats, range
+    TD_HIP(hipMemsetAsync(ctl, 0, CTL_ALL * sizeof(int), c.stream));  // flag, error, stats, range, shape
     const bool vec = (n % 4 == 0) && (((uintptr_t)sv.d_cost & 15) == 0);
     const int grid = std::max(1, std::min(nrows, c.n_cu * 8));
     sv.fused_bid0 = false;
@@ -1889,14 +2005,15 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false, bool bid0 = fa
         const int nq = n / 4;
         CT *cc = (CT *)sv.cc.p;
         int32_t *rm = (int32_t *)sv.rowmin.p;
+        int *rcs = (int *)sv.rconst.p;
         if (g_creg && vec && nq <= 256 * 16) {
             const int g2 = std::max(1, std::min(nrows, c.n_cu * g_cgrid));
 #define TD_CR(VPT)                                                                                                          \
     if (bid0)                                                                                                          \
-        k_compress_reg<CT, VPT, 256, true><<<g2, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl,       \
+        k_compress_reg<CT, VPT, 256, true><<<g2, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs,  \
                                                                     (unsigned long long *)sv.bid.p, sv.row0);          \
     else                                                                                                               \
-        k_compress_reg<CT, VPT, 256><<<g2, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl)
+        k_compress_reg<CT, VPT, 256><<<g2, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs)
             if (nq <= 256) { TD_CR(1); }
             else if (nq <= 512) { TD_CR(2); }
             else if (nq <= 1024) { TD_CR(4); }
@@ -1905,11 +2022,11 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false, bool bid0 = fa
 #undef TD_CR
             sv.fused_bid0 = bid0;
         } else if (g_creg && vec && nq <= 1024 * 16) {
-            k_compress_reg<CT, 16, 1024><<<std::max(1, std::min(nrows, c.n_cu * 2)), 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl);
+            k_compress_reg<CT, 16, 1024><<<std::max(1, std::min(nrows, c.n_cu * 2)), 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs);
         } else if (vec)
-            k_compress<CT, true><<<grid, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl);
+            k_compress<CT, true><<<grid, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs);
         else
-            k_compress<CT, false><<<grid, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl);
+            k_compress<CT, false><<<grid, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs);
     }
     TD_HIP(hipGetLastError());
     if (speculate) {
@@ -1948,7 +2065,7 @@ int sv_begin_t(Solver &sv)
     const PT padkey = (PT)(Tr<CT>::BIG << 1) | (PT)1;
     k_init_state<PT><<<(std::max(sv.npad, (int)CTL_WORDS) + 255) / 256, 256, 0, c.stream>>>(
         sv.n, sv.npad, sv.nrows, (PT *)sv.price.p, padkey, (int *)sv.owner.p, (int *)sv.r2c.p,
-        (unsigned long long *)sv.bid.p, (int *)sv.misc.p);
+        (unsigned long long *)sv.bid.p, (int *)sv.misc.p, sv.defer_const ? (const int *)sv.rconst.p : nullptr);
     TD_HIP(hipMemsetAsync((char *)sv.misc.p + 1024, 0, 16, c.stream));
     TD_HIP(hipGetLastError());
     return TD_OK;
@@ -2187,12 +2304,16 @@ int sv_readback(Solver &sv, int64_t *total, int64_t *dual, int max_rounds, int *
 {
     Ctx &c = ctx();
     char *pin = (char *)c.pinned;
-    TD_HIP(hipMemcpyAsync(pin, sv.misc.p, CTL_WORDS * sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    TD_HIP(hipMemcpyAsync(pin, sv.misc.p, CTL_ALL * sizeof(int), hipMemcpyDeviceToHost, c.stream));
     TD_HIP(hipMemcpyAsync(pin + 1024, (char *)sv.misc.p + 1024, 16, hipMemcpyDeviceToHost, c.stream));
     TD_HIP(hipStreamSynchronize(c.stream));
     const int *hctl = (const int *)pin;
     if (range_flag) {
         *range_flag = hctl[CTL_FLAG];
+        if (*range_flag & 4) {  // transposed formulation wanted: hand back the sampled column range
+            c.stats[6] = (int64_t)(((const unsigned long long *)(hctl + CTL_SHAPE + 4))[0]);
+            return TD_OK;
+        }
         if (*range_flag) {  // the speculated storage width was too narrow: caller retries
             c.stats[6] = (int64_t)(((const unsigned long long *)(hctl + CTL_RANGE))[0]);
             return TD_OK;
@@ -2255,10 +2376,15 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         return TD_OK;
     }
     const int max_rounds = g_max_rounds;
-    bool solved = false;
-    int64_t known_range = -1;
+    bool solved = false, transposed = false;
+    int64_t range_hint = -1;
+    sv.defer_const = g_defer_const && !g_solver_eps;
+    for (int orient = 0; orient < 2 && !solved; orient++) {
+    bool want_transpose = false;
+    int64_t known_range = transposed ? range_hint : -1;
     for (int bpc : {1, 2, 4}) {
         bool fits = false;
+        if (known_range > 254 && bpc == 1) continue;    // the probe's sampled column range: u8 cannot hold it
         if (known_range > 65534 && bpc == 2) continue;  // u16 cannot hold it either
         // the packed bid key keeps (price << 20 | row): prices stay below n * range
         if (known_range >= 0 && (double)(known_range + 1) * (double)(n + 1) >= 4.0e12)
@@ -2279,6 +2405,12 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         if (!fits) {
             known_range = c.stats[6];
             continue;
+        }
+        if (spec && orient == 0 && g_shape && n >= 64 && n <= g_shape_max_n && !g_solver_eps && !fuse0) {
+            // shape probe: may ask (CTL_FLAG bit 2) for the transposed formulation; like a failed
+            // width speculation this costs one empty pass through the early-exiting kernels
+            ProfScope ps(TD_K_FINAL);
+            k_shape<<<(n + 255) / 256, 256, 0, c.stream>>>(n, sv.d_cost, (int *)sv.misc.p);
         }
         if (!fuse0) {
             TD_DISPATCH(sv, sv_begin_t, sv);
@@ -2316,10 +2448,20 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         tab.count = 1;
         TD_DISPATCH(sv, sv_finish_t, sv, tab, (int *)sv.r2c.p);
         if (rc) return rc;
+        if (sv.defer_const) {
+            ProfScope ps(TD_K_FINAL);
+            k_place_const<<<1, 1024, 0, c.stream>>>(n, (int *)sv.r2c.p, (int *)sv.owner.p, (int *)sv.list.p, (int *)sv.pred.p,
+                                                   (int *)sv.misc.p);
+        }
         TD_DISPATCH(sv, sv_totals_t, sv, dual_bound != nullptr);
         if (rc) return rc;
         int flag = 0;
         if ((rc = sv_readback(sv, &tot, &dual, max_rounds, spec ? &flag : nullptr))) return rc;
+        if (spec && (flag & 4)) {  // many constant columns: solve the transposed problem instead
+            want_transpose = true;
+            range_hint = c.stats[6] > 254 ? c.stats[6] : -1;
+            break;
+        }
         if (spec && flag) {  // rows did not fit u8: redo with the width the recorded range needs
             known_range = c.stats[6];
             continue;
@@ -2327,11 +2469,24 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         solved = true;
         break;
     }
+    if (!want_transpose) break;
+    {
+        ProfScope ps(TD_K_FINAL);
+        if ((rc = ensure(sv.tbuf, sizeof(int32_t) * (size_t)n * n))) return rc;
+        k_transpose<<<dim3((n + 63) / 64, (n + 63) / 64), 256, 0, c.stream>>>(n, sv.d_cost, (int32_t *)sv.tbuf.p);
+        TD_HIP(hipGetLastError());
+        sv.d_cost = (const int32_t *)sv.tbuf.p;
+        transposed = true;
+    }
+    }
     if (!solved) return fail(TD_ERANGE, "row cost range exceeds 2^32-2");
+    // transposed solve: its columns are the caller's rows, owner[] is the caller's row_to_col
+    const void *res = transposed ? sv.owner.p : sv.r2c.p;
+    c.stats[7] = transposed ? 1 : 0;
     if (is_device_ptr(row_to_col)) {
-        TD_HIP(hipMemcpyAsync(row_to_col, sv.r2c.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c.stream));
+        TD_HIP(hipMemcpyAsync(row_to_col, res, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c.stream));
     } else {
-        TD_HIP(hipMemcpyAsync(row_to_col, sv.r2c.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipMemcpyAsync(row_to_col, res, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c.stream));
     }
     TD_HIP(hipStreamSynchronize(c.stream));
     if (total) *total = tot;

@@ -284,10 +284,27 @@ __global__ __launch_bounds__(256) void k_lcms_minmax(int n, const int32_t *__res
         mx = max(mx, __shfl_xor(mx, o));
         cnt += __shfl_xor(cnt, o);
     }
-    if ((threadIdx.x & 63) == 0 && cnt) {
-        atomicMin(&info->vmin, mn);
-        atomicMax(&info->vmax, mx);
-        atomicAdd((unsigned long long *)&info->count, (unsigned long long)cnt);
+    // one set of atomics per workgroup (thousands of same-address atomics cost more than the scan)
+    __shared__ int s_mn[4], s_mx[4];
+    __shared__ long long s_cnt[4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_mn[w] = mn;
+        s_mx[w] = mx;
+        s_cnt[w] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) {
+            mn = min(mn, s_mn[k]);
+            mx = max(mx, s_mx[k]);
+            cnt += s_cnt[k];
+        }
+        if (cnt) {
+            atomicMin(&info->vmin, mn);
+            atomicMax(&info->vmax, mx);
+            atomicAdd((unsigned long long *)&info->count, (unsigned long long)cnt);
+        }
     }
 }
 
@@ -543,7 +560,7 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
             ProfScope ps(TD_K_LCM);
             TD_HIP(hipMemcpyAsync(d_info, &init, sizeof(init), hipMemcpyHostToDevice, c.stream));
             const int64_t cellsN = (int64_t)n * n;
-            const int grid = (int)std::min<int64_t>((cellsN + 1023) / 1024, (int64_t)c.n_cu * 8);
+            const int grid = (int)std::min<int64_t>((cellsN + 4095) / 4096, (int64_t)c.n_cu * 4);
             k_lcms_minmax<<<grid, 256, 0, c.stream>>>(n, d_cost, hi, d_info);
         }
         TD_HIP(hipMemcpyAsync(c.pinned, d_info, sizeof(LcmsInfo), hipMemcpyDeviceToHost, c.stream));

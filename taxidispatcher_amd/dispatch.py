@@ -106,7 +106,7 @@ def last_stats():
     out = (ctypes.c_int64 * 8)()
     _ffi.check(_ffi.lib().td_last_stats(out, 8))
     return {"bid_rounds": out[0], "sap_free_rows": out[2], "sap_steps": out[3], "bytes_per_cell": out[4],
-            "parallel_sap_rows": out[5]}
+            "parallel_sap_rows": out[5], "transposed": out[7]}
 
 
 # ----------------------------------------------------------------------------------------

@@ -201,6 +201,38 @@ def test_reference_shaped_calculate_cost_and_solve(td):
     assert td.solve(dist, [], [], drop_time=10) == (0, [], 0)
 
 
+def test_rectangular_models_constant_rows_and_columns(td):
+    """Padded rectangular models (solver.py pads to a square with big_cost; Simulator.java:244-252):
+    constant rows are deferred, many constant columns switch td_assign to the transposed
+    formulation - total, dual certificate and permutation must match the oracle either way."""
+    rng = np.random.default_rng(99)
+    seen_t = 0
+    for trial in range(60):
+        n = int(rng.choice([64, 65, 100, 257, 600, 1300]))
+        real_r = int(rng.integers(1, n + 1))
+        real_c = int(rng.integers(1, n + 1))
+        if trial % 3 == 0:
+            real_r, real_c = n, int(rng.integers(1, max(2, n // 2)))     # dummy columns dominate
+        c = np.full((n, n), BIG, np.int32)
+        blk = rng.integers(0, int(rng.choice([10, 50, 100000])), (real_r, real_c)).astype(np.int32)
+        if trial % 2 == 0:   # DROP_TIME style threshold inside the real block
+            blk[rng.random(blk.shape) < 0.7] = BIG
+        c[:real_r, :real_c] = blk
+        if trial % 5 == 0:   # constant rows / columns need not share one value
+            c[real_r:, :] = rng.integers(0, 1000, (n - real_r, 1)).astype(np.int32)
+        if trial % 7 == 0:
+            c = c[rng.permutation(n)][:, rng.permutation(n)]
+        c = np.ascontiguousarray(c)
+        r2c, total, dual = td.assign(c, n, want_dual=True)
+        t_o = oracle.assign(c)[0]
+        assert total == t_o == dual, (trial, n, real_r, real_c, total, t_o, dual)
+        r2c = np.asarray(r2c)
+        assert sorted(r2c.tolist()) == list(range(n))
+        assert int(c[np.arange(n), r2c].astype(np.int64).sum()) == t_o
+        seen_t += td.last_stats()["transposed"]
+    assert seen_t >= 10   # the transposed path was exercised
+
+
 def test_lcm_randomized_differential(td):
     """td_lcm against the oracle over random shapes of every stop rule: threshold, stop value,
     stop size, pair cap, masked cells, exhausted lists; instances with few value levels take the
