@@ -102,8 +102,11 @@ int g_fuse_bid0 = 0;        // TD_FUSE_BID0     round 0 inside the compress pass
 int g_sap8 = 1;             // TD_SAP8          lean u8 finisher
 int g_psap8_batches = 1;    // TD_PSAP8         speculative batches of the lean u8 search
 int g_psap8_grid = 64;      // TD_PSAP8_GRID    searches per such batch
-int g_psap_batches = 16;    // TD_PSAP          max speculative batches of the generic search (u16 / u32 rows)
+int g_psap_batches = 16;    // TD_PSAP          speculative batches per group of the generic search (u16 / u32 rows)
 int g_psap_min = 12;        // TD_PSAP_MIN      free rows below which the generic batches are skipped
+int g_psap_cap = 4096;      // TD_PSAP_CAP      total speculative batches per solve
+int g_sap512 = 1;           // TD_SAP512        512-thread generic finisher (double register budget) for n <= 8192
+int g_psap_worth = 8;       // TD_PSAP_WORTH    rows a batch must commit on average for another group to be launched
 int g_psap_u8 = 0;          // TD_PSAP_U8       generic batches for u8 rows too (slower than the lean path)
 int g_onewave = 0;          // TD_ONEWAVE       single-wavefront generic finisher for small models (no gain)
 int g_defer_const = 1;      // TD_DEFER_CONST   constant rows sit out the solve (k_place_const)
@@ -126,6 +129,9 @@ void read_tunables()
     if (const char *e = getenv("TD_CREG")) g_creg = atoi(e) != 0;
     if (const char *e = getenv("TD_PSAP")) g_psap_batches = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("TD_PSAP_MIN")) g_psap_min = std::max(1, atoi(e));
+    if (const char *e = getenv("TD_PSAP_CAP")) g_psap_cap = std::max(0, atoi(e));
+    if (const char *e = getenv("TD_SAP512")) g_sap512 = atoi(e) != 0;
+    if (const char *e = getenv("TD_PSAP_WORTH")) g_psap_worth = std::max(1, atoi(e));
     if (const char *e = getenv("TD_PSAP_U8")) g_psap_u8 = atoi(e) != 0;
     if (const char *e = getenv("TD_SPECULATE")) g_speculate = atoi(e) != 0;
     if (const char *e = getenv("TD_FUSE_BID0")) g_fuse_bid0 = atoi(e) != 0;
@@ -952,8 +958,21 @@ __device__ __forceinline__ const CT *shard_row(const ShardTab &tab, int o, size_
     return reinterpret_cast<const CT *>(tab.p[sh]) + (size_t)(o - sh * tab.rps) * pitch;
 }
 
-template <typename CT, int CH, bool LDSST>
-__global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab tab,
+#ifndef TD_G512
+#define TD_G512 8
+#endif
+#ifndef TD_G_U32
+#define TD_G_U32 4
+#endif
+#ifndef TD_RELAX_ANY
+#define TD_RELAX_ANY 1
+#endif
+constexpr int SAPB_W = 16;  // generic finisher: columns scanned per step (frontier + window)
+
+// TB: largest workgroup the instance is launched with. 512 threads halve the waves per SIMD and so
+// double the register budget (256 VGPRs), which is what lets a step keep 8-16 rows in flight.
+template <typename CT, int CH, bool LDSST, int TB = 1024>
+__global__ __launch_bounds__(TB) void k_sap(int n, int nchunks, const ShardTab tab,
                                               typename Tr<CT>::PT *__restrict__ pk, int *__restrict__ owner_g,
                                               int *__restrict__ r2c, int *__restrict__ pred_g, int *__restrict__ list,
                                               int *__restrict__ ctl)
@@ -973,8 +992,10 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab
     __shared__ PT s_rp[2][16];
     __shared__ int s_rj[2][16];
     __shared__ int s_ro[2][16];
+    // batch of columns finalised together in one step (see the step loop)
+    __shared__ PT s_bd[SAPB_W], s_bp[SAPB_W];
+    __shared__ int s_bcol[SAPB_W], s_bown[SAPB_W];
     __shared__ int s_wcnt[16];
-    __shared__ int s_nfree;
 
     if (ctl[CTL_FLAG]) return;
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
@@ -1007,6 +1028,7 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab
     long long steps = 0;
     int par = 0;
     bool bad = false;
+    PT delta = 0;   // batch window above the frontier distance, adapted step by step (wave-uniform)
     // own prices stay in registers for the whole kernel when they fit (PREG): a thread is the
     // only writer of its columns' prices, so global memory sees them once, at the end
     PT preg[PREG ? NV : 1];
@@ -1044,6 +1066,7 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab
             }
         }
         PT d[NV];
+        PT dp[NV];   // d - price, the per-column side of the relax test; pad columns can never improve
         int ownr[PREG ? NV : 1];
         unsigned long long scanned = padmask;
         // bit set <=> the column has an owner (or does not exist).  Folded into the argmin key
@@ -1066,12 +1089,14 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab
                     if (PREG) ownr[q * E + e] = o;
                     if (o != -1) ownedmask |= 1ull << (q * E + e);
                     d[q * E + e] = (PT)c[e] + p;
+                    dp[q * E + e] = (j < n) ? (PT)c[e] : -(KMAX >> 2);
                     PRED[j] = -1;   // predecessor COLUMN; -1 = reached from the root row
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     d[q * E + e] = KMAX >> 2;
+                    dp[q * E + e] = -(KMAX >> 2);
                     if (PREG) ownr[q * E + e] = -2;
                 }
             }
@@ -1128,29 +1153,123 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab
             }
             const int o = PREG ? bo : OWN[bj];
             steps++;
-            {  // mark scanned
-                const int chq = bj / E;
-                if ((chq % T) == tid) scanned |= 1ull << ((chq / T) * E + (bj - chq * E));
+            // ---- batch: besides the frontier column bj, up to SAPB_W-1 more owned, not yet
+            // scanned columns within `delta` of the frontier distance are scanned in the same
+            // step (their owners' rows are streamed together: one memory round trip and one
+            // barrier pair instead of one per column). Their labels need not be final: a column
+            // whose label drops after it was scanned becomes unscanned again (label-correcting),
+            // so at the end every column below the end distance carries its exact distance
+            // (argument in DESIGN.md, "batched finisher steps") and ties / paths stay exact.
+            unsigned long long cand = 0ull;
+            {
+                const PT lim = bd + delta;
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    const bool ok = !((scanned >> k) & 1ull) && ((ownedmask >> k) & 1ull) && !((padmask >> k) & 1ull) &&
+                                    d[k] <= lim;
+                    cand |= ok ? (1ull << k) : 0ull;
+                }
+                const int chq = bj / E;   // the frontier column is entry 0, not a candidate
+                if ((chq % T) == tid) {
+                    const unsigned long long bit = 1ull << ((chq / T) * E + (bj - chq * E));
+                    cand &= ~bit;
+                    scanned |= bit;
+                }
             }
-            // stream the row of the column's owner and relax
-            const CT *rp = shard_row<CT>(tab, o, pitch);
-            const PT wstar = (PT)rp[bj] + (PREG ? bp : P[bj]);  // (o, bj) is tight: o's row dual
+            const int mycnt = __popcll(cand);
+            int incl = mycnt;
 #pragma unroll
-            for (int q = 0; q < CH; q++) {
-                const int ch = q * T + tid;
-                if (ch < nchunks) {
-                    const uint4 cv = *reinterpret_cast<const uint4 *>(rp + (size_t)ch * E);
-                    uint32_t c[E];
-                    unpack<CT>(cv, c);
+            for (int sh = 1; sh < 64; sh <<= 1) {
+                const int v = __shfl_up(incl, sh);
+                if (lane >= sh) incl += v;
+            }
+            if (lane == 63) s_wcnt[w] = incl;
+            if (tid == 0) {
+                s_bcol[0] = bj;
+                s_bd[0] = bd;
+                s_bown[0] = o;
+                s_bp[0] = PREG ? bp : P[bj];
+            }
+            __syncthreads();
+            int base = 1, total = 0;   // slot 0 is the frontier column
+            for (int q = 0; q < nw; q++) {
+                const int cw = s_wcnt[q];
+                base += (q < w) ? cw : 0;
+                total += cw;
+            }
+            {
+                int pos = base + incl - mycnt;
 #pragma unroll
-                    for (int e = 0; e < E; e++) {
-                        const int j = ch * E + e;
-                        const PT p = PREG ? preg[q * E + e] : P[j];
-                        const PT h = bd + ((PT)c[e] + p - wstar);
-                        const bool ok = !((scanned >> (q * E + e)) & 1ull);
-                        if (ok && h < d[q * E + e]) {
-                            d[q * E + e] = h;
-                            PRED[j] = bj;
+                for (int k = 0; k < NV; k++) {
+                    if (((cand >> k) & 1ull) && pos < SAPB_W) {
+                        const int jc = ((k / E) * T + tid) * E + (k % E);
+                        s_bcol[pos] = jc;
+                        s_bd[pos] = d[k];
+                        s_bown[pos] = PREG ? ownr[k] : OWN[jc];
+                        s_bp[pos] = PREG ? preg[k] : P[jc];
+                        scanned |= 1ull << k;
+                        pos++;
+                    }
+                }
+            }
+            const int nb = min(total + 1, SAPB_W);
+            // window control: aim at a batch that is about full
+            if (total + 1 > SAPB_W)
+                delta >>= 1;
+            else if (total + 1 <= SAPB_W / 2)
+                delta = (delta < (KMAX >> 4)) ? delta * 2 + 1 : delta;
+            __syncthreads();
+            // stream the rows of the batch columns' owners and relax; SAPB_G rows in flight at a time
+            constexpr int SAPB_G = (TB <= 512) ? ((NV <= 8) ? TD_G512 : 8) : ((CH == 1) ? ((E == 4) ? TD_G_U32 : 4) : ((CH == 2) ? 2 : 1));
+            for (int e0 = 0; e0 < nb; e0 += SAPB_G) {
+                uint4 cv[SAPB_G][CH];
+                PT wst[SAPB_G], de[SAPB_G];
+                int ce[SAPB_G];
+                // branch-free: slots past the batch repeat its last entry (relaxing twice is harmless),
+                // so all loads of the group are issued back to back
+#pragma unroll
+                for (int g = 0; g < SAPB_G; g++) {
+                    const int e = min(e0 + g, nb - 1);
+                    const int oc = s_bown[e];
+                    ce[g] = s_bcol[e];
+                    de[g] = s_bd[e];
+                    const CT *rp = shard_row<CT>(tab, oc, pitch);
+                    wst[g] = (PT)rp[ce[g]] + s_bp[e];   // (owner, column) is tight: the owner's row dual
+#pragma unroll
+                    for (int q = 0; q < CH; q++) {
+                        const int ch = min(q * T + tid, nchunks - 1);
+                        cv[g][q] = *reinterpret_cast<const uint4 *>(rp + (size_t)ch * E);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < SAPB_G; g++) {
+                    // label through this row: h = de + (c + p - wst). The test h < d is done as
+                    // (de - wst) + c < d - p: the right side is per column and changes only on the
+                    // rare improvement, so the common case costs one 64-bit add and one compare.
+                    const PT bs = de[g] - wst[g];
+#pragma unroll
+                    for (int q = 0; q < CH; q++) {
+                        uint32_t c[E];
+                        unpack<CT>(cv[g][q], c);
+#if TD_RELAX_ANY
+                        bool any = false;
+#pragma unroll
+                        for (int x = 0; x < E; x++) any = any || (bs + (PT)c[x] < dp[q * E + x]);
+                        if (any)
+#endif
+                        {
+#pragma unroll
+                            for (int x = 0; x < E; x++) {
+                                const int k = q * E + x;
+                                const PT t = bs + (PT)c[x];
+                                if (t < dp[k]) {
+                                    const PT p = PREG ? preg[k] : P[(q * T + tid) * E + x];
+                                    dp[k] = t;
+                                    d[k] = t + p;
+                                    PRED[(q * T + tid) * E + x] = ce[g];
+                                    scanned &= ~(1ull << k);   // (re)opened
+                                }
+                            }
                         }
                     }
                 }
@@ -1166,7 +1285,7 @@ __global__ __launch_bounds__(1024) void k_sap(int n, int nchunks, const ShardTab
         for (int q = 0; q < CH; q++) {
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                if ((upd >> (q * E + e)) & 1ull) {
+                if (((upd >> (q * E + e)) & 1ull) && d[q * E + e] < mind) {
                     const int j = (q * T + tid) * E + e;
                     if (PREG)
                         preg[q * E + e] += mind - d[q * E + e];
@@ -1536,7 +1655,7 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
 // Results do not depend on workgroup timing: searches of a batch share one snapshot and the
 // claim is a min over ids.
 // =====================================================================================
-template <typename CT, bool LDSST>
+template <typename CT, int CH, bool LDSST>
 __global__ __launch_bounds__(1024) void k_psearch(int n, int nchunks, const ShardTab tab,
                                                   const typename Tr<CT>::PT *__restrict__ pk,
                                                   const int *__restrict__ owner_g, int *__restrict__ pred_g,
@@ -1545,6 +1664,11 @@ __global__ __launch_bounds__(1024) void k_psearch(int n, int nchunks, const Shar
 {
     using PT = typename Tr<CT>::PT;
     constexpr int E = Tr<CT>::E;
+    constexpr int NV = CH * E;   // columns per thread: chunk q*T + tid, q = 0..CH-1 (as k_sap)
+    static_assert(NV <= 32, "column masks are 32 bits");
+    // owners ride along in registers only while they fit (128 VGPRs at 1024 threads); otherwise the
+    // winner's owner is one LDS read after the argmin
+    constexpr bool OREG = (NV * (int)sizeof(PT) / 4) <= 16 || !LDSST;
     constexpr PT KMAX = Tr<CT>::KMAX;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ PT s_rk[2][16];
@@ -1572,31 +1696,35 @@ __global__ __launch_bounds__(1024) void k_psearch(int n, int nchunks, const Shar
         for (int j = tid; j < npad; j += T) OWN[j] = owner_g[j];
         __syncthreads();
     }
-    const bool has = tid < nchunks;
-    const int jbase = tid * E;
-    PT d[E], preg[E];
-    int ownr[E];
+    PT d[NV], preg[NV];
+    int ownr[OREG ? NV : 1];
     uint32_t scanned = 0, owned = 0, valid = 0;
     {
-        uint32_t c[E];
-        if (has) {
-            const uint4 cv = *reinterpret_cast<const uint4 *>(shard_row<CT>(tab, f, pitch) + (size_t)jbase);
-            unpack<CT>(cv, c);
-        }
+        const CT *frow = shard_row<CT>(tab, f, pitch);
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int j = jbase + e;
-            const bool ok = has && j < n;
-            const PT p = ok ? (PT)(pk[j] >> 1) : (PT)0;
-            const int o = ok ? (LDSST ? OWN[j] : owner_g[j]) : -2;
-            preg[e] = p;
-            ownr[e] = o;
-            d[e] = ok ? (PT)c[e] + p : (KMAX >> 2);
-            if (ok) {
-                valid |= 1u << e;
-                PRED[j] = -1;
+        for (int q = 0; q < CH; q++) {
+            const int ch = q * T + tid;
+            const bool has = ch < nchunks;
+            uint32_t c[E];
+            if (has) {
+                const uint4 cv = *reinterpret_cast<const uint4 *>(frow + (size_t)ch * E);
+                unpack<CT>(cv, c);
             }
-            if (o != -1) owned |= 1u << e;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int j = ch * E + e;
+                const bool ok = has && j < n;
+                const PT p = ok ? (PT)(pk[j] >> 1) : (PT)0;
+                const int o = ok ? (LDSST ? OWN[j] : owner_g[j]) : -2;
+                preg[q * E + e] = p;
+                if (OREG) ownr[q * E + e] = o;
+                d[q * E + e] = ok ? (PT)c[e] + p : (KMAX >> 2);
+                if (ok) {
+                    valid |= 1u << (q * E + e);
+                    PRED[j] = -1;
+                }
+                if (o != -1) owned |= 1u << (q * E + e);
+            }
         }
     }
     int steps = 0, par = 0, endcol = -1, status = 1;
@@ -1605,16 +1733,20 @@ __global__ __launch_bounds__(1024) void k_psearch(int n, int nchunks, const Shar
         PT bk = KMAX, bp = 0;
         int bj = INT_MAX, bo = -2;
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const bool ok = ((valid >> e) & 1u) && !((scanned >> e) & 1u);
-            const PT v = (PT)(d[e] << 1) | (PT)((owned >> e) & 1u);
-            int jr = jbase + e - rot;
-            jr += (jr < 0) ? npad : 0;
-            if (ok && (v < bk || (v == bk && jr < bj))) {
-                bk = v;
-                bj = jr;  // rotated index while reducing
-                bo = ownr[e];
-                bp = preg[e];
+        for (int q = 0; q < CH; q++) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int k = q * E + e;
+                const bool ok = ((valid >> k) & 1u) && !((scanned >> k) & 1u);
+                const PT v = (PT)(d[k] << 1) | (PT)((owned >> k) & 1u);
+                int jr = (q * T + tid) * E + e - rot;
+                jr += (jr < 0) ? npad : 0;
+                if (ok && (v < bk || (v == bk && jr < bj))) {
+                    bk = v;
+                    bj = jr;  // rotated index while reducing
+                    if (OREG) bo = ownr[k];
+                    bp = preg[k];
+                }
             }
         }
         wave_argmin<PT>(bk, bj, bo, bp);
@@ -1640,18 +1772,20 @@ __global__ __launch_bounds__(1024) void k_psearch(int n, int nchunks, const Shar
         }
         bj += rot;  // back to the column index
         bj -= (bj >= npad) ? npad : 0;
+        if (!OREG) bo = OWN[bj];
         const PT bd = bk >> 1;
         if (!(bk & 1)) {
             // A free column is at the frontier distance.  Usually a whole class of free columns
             // is tied there (dummy columns of a simulator model): take the k-th of them, k spread
             // over the searches of the batch, so that concurrent searches end in DIFFERENT columns
             // instead of rejecting each other at commit.
-            int mycnt = 0;
+            uint32_t tiemask = 0;
 #pragma unroll
-            for (int e = 0; e < E; e++) {
-                const bool tie = ((valid >> e) & 1u) && !((scanned >> e) & 1u) && !((owned >> e) & 1u) && d[e] == bd;
-                mycnt += tie ? 1 : 0;
+            for (int k = 0; k < NV; k++) {
+                const bool tie = ((valid >> k) & 1u) && !((scanned >> k) & 1u) && !((owned >> k) & 1u) && d[k] == bd;
+                tiemask |= tie ? (1u << k) : 0u;
             }
+            const int mycnt = __popc(tiemask);
             int incl = mycnt;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -1671,10 +1805,9 @@ __global__ __launch_bounds__(1024) void k_psearch(int n, int nchunks, const Shar
             if (target >= lo && target < lo + mycnt) {
                 int skip = target - lo;
 #pragma unroll
-                for (int e = 0; e < E; e++) {
-                    const bool tie = ((valid >> e) & 1u) && !((scanned >> e) & 1u) && !((owned >> e) & 1u) && d[e] == bd;
-                    if (tie) {
-                        if (skip == 0) s_rj[par ^ 1][0] = jbase + e;
+                for (int k = 0; k < NV; k++) {
+                    if ((tiemask >> k) & 1u) {
+                        if (skip == 0) s_rj[par ^ 1][0] = ((k / E) * T + tid) * E + (k % E);
                         skip--;
                     }
                 }
@@ -1694,20 +1827,28 @@ __global__ __launch_bounds__(1024) void k_psearch(int n, int nchunks, const Shar
             rec->S_d[steps] = bd;
         }
         steps++;
-        if (tid == (bj / E)) scanned |= 1u << (bj - (bj / E) * E);
+        {
+            const int chq = bj / E;
+            if ((chq % T) == tid) scanned |= 1u << ((chq / T) * E + (bj - chq * E));
+        }
         const CT *rp = shard_row<CT>(tab, bo, pitch);
         const PT wstar = (PT)rp[bj] + bp;
-        if (has) {
-            const uint4 cv = *reinterpret_cast<const uint4 *>(rp + (size_t)jbase);
-            uint32_t c[E];
-            unpack<CT>(cv, c);
 #pragma unroll
-            for (int e = 0; e < E; e++) {
-                const PT h = bd + ((PT)c[e] + preg[e] - wstar);
-                const bool ok = ((valid >> e) & 1u) && !((scanned >> e) & 1u);
-                if (ok && h < d[e]) {
-                    d[e] = h;
-                    PRED[jbase + e] = bj;  // predecessor COLUMN (the path walk then needs no row->col map)
+        for (int q = 0; q < CH; q++) {
+            const int ch = q * T + tid;
+            if (ch < nchunks) {
+                const uint4 cv = *reinterpret_cast<const uint4 *>(rp + (size_t)ch * E);
+                uint32_t c[E];
+                unpack<CT>(cv, c);
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const int k = q * E + e;
+                    const PT h = bd + ((PT)c[e] + preg[k] - wstar);
+                    const bool ok = ((valid >> k) & 1u) && !((scanned >> k) & 1u);
+                    if (ok && h < d[k]) {
+                        d[k] = h;
+                        PRED[ch * E + e] = bj;  // predecessor COLUMN (the path walk then needs no row->col map)
+                    }
                 }
             }
         }
@@ -2111,15 +2252,15 @@ int sv_apply_t(Solver &sv, int r, unsigned long long *keys)
     return TD_OK;
 }
 
-template <typename CT, int CH, bool LDSST>
+template <typename CT, int CH, bool LDSST, int TB = 1024>
 void launch_sap(Solver &sv, const ShardTab &tab, int *r2c_full, int T, size_t shm)
 {
     Ctx &c = ctx();
     using PT = typename Tr<CT>::PT;
     if (shm > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)k_sap<CT, CH, LDSST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    k_sap<CT, CH, LDSST><<<1, T, shm, c.stream>>>(sv.n, sv.nchunks, tab, (PT *)sv.price.p, (int *)sv.owner.p, r2c_full,
-                                                  (int *)sv.pred.p, (int *)sv.list.p, (int *)sv.misc.p);
+        (void)hipFuncSetAttribute((const void *)k_sap<CT, CH, LDSST, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    k_sap<CT, CH, LDSST, TB><<<1, T, shm, c.stream>>>(sv.n, sv.nchunks, tab, (PT *)sv.price.p, (int *)sv.owner.p, r2c_full,
+                                                      (int *)sv.pred.p, (int *)sv.list.p, (int *)sv.misc.p);
 }
 
 // finisher; r2c_full is indexed by GLOBAL row (== sv.r2c for an unsharded solve)
@@ -2147,32 +2288,58 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
     k_freelist<<<1, 1024, 0, ctx().stream>>>(n, r2c_full, (int *)sv.list.p, (int *)sv.misc.p);
     // ---- speculative parallel searches first (a few batches), the serial workgroup mops up
     // (u8 instances go straight to the lean tie-batching serial workgroup, which is faster there)
-    if (g_psap_batches > 0 && CH == 1 && lds && n >= 64 && (sizeof(CT) > 1 || g_psap_u8)) {
+    if (g_psap_batches > 0 && CH <= 4 && CH * E <= 16 && lds && n >= 64 && (sizeof(CT) > 1 || g_psap_u8)) {
         Ctx &c = ctx();
         using PT = typename Tr<CT>::PT;
         int rc = ensure(sv.psrec, sizeof(PsRec<PT>) * (size_t)PS_G);
         if (rc) return rc;
         PsRec<PT> *recs = (PsRec<PT> *)sv.psrec.p;
         const size_t cshm = 2 * sizeof(int) * (size_t)n;
-        if (shm > 48 * 1024)
-            (void)hipFuncSetAttribute((const void *)k_psearch<CT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (cshm > 48 * 1024)
             (void)hipFuncSetAttribute((const void *)k_pcommit<PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cshm);
         unsigned long long *raise = (unsigned long long *)sv.bid.p;  // all zero after the bidding rounds
-        // one small read-back decides how many speculative batches are worth launching: with a
-        // handful of free rows the serial (tie-batching) workgroup is faster than any batch
-        TD_HIP(hipMemcpyAsync(c.pinned, (int *)sv.misc.p + CTL_NFREE, sizeof(int), hipMemcpyDeviceToHost, c.stream));
-        TD_HIP(hipStreamSynchronize(c.stream));
-        const int nfree0 = ((int *)c.pinned)[0];
-        int batches = 0;
-        if (nfree0 >= g_psap_min) batches = std::min(g_psap_batches, (nfree0 + 31) / 32);
-        for (int b = 0; b < batches; b++) {
-            k_psearch<CT, true><<<PS_G, T, shm, c.stream>>>(n, nchunks, tab, (const PT *)sv.price.p, (const int *)sv.owner.p,
-                                                           (int *)sv.pred.p, (const int *)sv.list.p, (const int *)sv.misc.p, recs);
-            k_pcommit<PT><<<1, 1024, cshm, c.stream>>>(n, (PT *)sv.price.p, (int *)sv.owner.p, r2c_full, (int *)sv.list.p,
-                                                       (int *)sv.misc.p, raise, recs, 0);
+        auto search = [&]() {
+#define TD_PS(CHV)                                                                                                         \
+    if constexpr (CHV * E <= 16) {                                                                                         \
+        if (shm > 48 * 1024)                                                                                               \
+            (void)hipFuncSetAttribute((const void *)k_psearch<CT, CHV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)shm);                                                                           \
+        k_psearch<CT, CHV, true><<<PS_G, T, shm, c.stream>>>(n, nchunks, tab, (const PT *)sv.price.p,                     \
+                                                            (const int *)sv.owner.p, (int *)sv.pred.p,                     \
+                                                            (const int *)sv.list.p, (const int *)sv.misc.p, recs);         \
+    }
+            if (CH == 1) { TD_PS(1) }
+            else if (CH == 2) { TD_PS(2) }
+            else { TD_PS(4) }
+#undef TD_PS
+        };
+        // Batches go out in groups; one small read-back of the free-row count per group decides
+        // whether another group is worth it. With a handful of free rows the serial workgroup
+        // is faster than any batch, and a group that commits fewer than two rows per batch means
+        // the searches have started to collide (or to run over the record length).
+        auto read_nfree = [&](int *out) -> int {
+            TD_HIP(hipMemcpyAsync(c.pinned, (int *)sv.misc.p + CTL_NFREE, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+            TD_HIP(hipStreamSynchronize(c.stream));
+            *out = ((int *)c.pinned)[0];
+            return TD_OK;
+        };
+        int nfree = 0, launched = 0;
+        if ((rc = read_nfree(&nfree))) return rc;
+        while (nfree >= g_psap_min && launched < g_psap_cap) {
+            const int nb = std::max(1, std::min(g_psap_batches, (nfree + 31) / 32));
+            for (int b = 0; b < nb; b++) {
+                search();
+                k_pcommit<PT><<<1, 1024, cshm, c.stream>>>(n, (PT *)sv.price.p, (int *)sv.owner.p, r2c_full, (int *)sv.list.p,
+                                                           (int *)sv.misc.p, raise, recs, 0);
+            }
+            launched += nb;
+            TD_HIP(hipGetLastError());
+            int left = 0;
+            if ((rc = read_nfree(&left))) return rc;
+            const bool worth = (nfree - left) >= g_psap_worth * nb;
+            nfree = left;
+            if (!worth) break;
         }
-        TD_HIP(hipGetLastError());
     }
     if constexpr (sizeof(CT) == 1) {
         if (CH == 1 && g_sap8) {
@@ -2207,6 +2374,26 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
                 k_sap8<false, false><<<1, T, 0, c.stream>>>(sv.n, sv.nchunks, tab, (int32_t *)sv.price.p, (int *)sv.owner.p, r2c_full,
                                                             (int *)sv.pred.p, (int *)sv.list.p, (int *)sv.misc.p, nullptr);
             }
+            TD_HIP(hipGetLastError());
+            return TD_OK;
+        }
+    }
+    {   // 512-thread instance: same code compiled for a 256-VGPR budget (more rows in flight per step)
+        int ch5 = 1;
+        while (ch5 * 512 < nchunks) ch5 *= 2;
+        // (measured: only a win when the workgroup has <= 512 threads anyway, i.e. no wave is given up)
+        if (g_sap512 && ch5 == CH && ch5 * E <= 16 && !(g_onewave && CH * E <= g_onewave)) {
+            int T5 = (nchunks + ch5 - 1) / ch5;
+            T5 = std::min(512, std::max(64, ((T5 + 63) / 64) * 64));
+#define TD_SAP5(CHV)                                                               \
+    if constexpr (CHV * E <= 16) {                                                 \
+        if (lds) launch_sap<CT, CHV, true, 512>(sv, tab, r2c_full, T5, shm);       \
+        else launch_sap<CT, CHV, false, 512>(sv, tab, r2c_full, T5, shm);          \
+    }
+            if (ch5 == 1) { TD_SAP5(1) }
+            else if (ch5 == 2) { TD_SAP5(2) }
+            else { TD_SAP5(4) }
+#undef TD_SAP5
             TD_HIP(hipGetLastError());
             return TD_OK;
         }
