@@ -83,6 +83,7 @@ enum {
     // shape probe (k_shape): [+0] constant-looking columns, [+1] rows, [+2] block ticket,
     // [+3] 1 = solve the transpose, [+4..5] 64-bit largest sampled column range
     CTL_SHAPE = CTL_WORDS,
+    CTL_PSTOP = CTL_WORDS + 6,   // a speculative batch committed nothing: later batches of the group exit at once
     CTL_ALL = CTL_WORDS + 8
 };
 
@@ -106,7 +107,7 @@ int g_psap_batches = 16;    // TD_PSAP          speculative batches per group of
 int g_psap_min = 12;        // TD_PSAP_MIN      free rows below which the generic batches are skipped
 int g_psap_cap = 4096;      // TD_PSAP_CAP      total speculative batches per solve
 int g_sap512 = 1;           // TD_SAP512        512-thread generic finisher (double register budget) for n <= 8192
-int g_psap_worth = 8;       // TD_PSAP_WORTH    rows a batch must commit on average for another group to be launched
+int g_psap_worth = 4;       // TD_PSAP_WORTH    rows a batch must commit on average for another group to be launched
 int g_psap_u8 = 0;          // TD_PSAP_U8       generic batches for u8 rows too (slower than the lean path)
 int g_onewave = 0;          // TD_ONEWAVE       single-wavefront generic finisher for small models (no gain)
 int g_defer_const = 1;      // TD_DEFER_CONST   constant rows sit out the solve (k_place_const)
@@ -958,6 +959,19 @@ __device__ __forceinline__ const CT *shard_row(const ShardTab &tab, int o, size_
     return reinterpret_cast<const CT *>(tab.p[sh]) + (size_t)(o - sh * tab.rps) * pitch;
 }
 
+constexpr int PS_G = 192;     // searches per batch
+constexpr int PS_CAP = 4096;  // finalised columns recorded per search; longer searches are left to the serial finisher
+
+template <typename PT>
+struct PsRec {
+    int f, endcol, nS, plen, status;  // status 1 = usable
+    int pad[3];
+    PT mind;
+    int S_col[PS_CAP];
+    PT S_d[PS_CAP];
+    int path[PS_CAP + 2];
+};
+
 #ifndef TD_G512
 #define TD_G512 8
 #endif
@@ -971,11 +985,14 @@ constexpr int SAPB_W = 16;  // generic finisher: columns scanned per step (front
 
 // TB: largest workgroup the instance is launched with. 512 threads halve the waves per SIMD and so
 // double the register budget (256 VGPRs), which is what lets a step keep 8-16 rows in flight.
-template <typename CT, int CH, bool LDSST, int TB = 1024>
+// SPEC = false: the serial finisher (applies every augmentation itself).
+// SPEC = true : one speculative search per workgroup against a read-only snapshot (nothing global
+//               is written but the record recs[blockIdx.x], applied or rejected by k_pcommit).
+template <typename CT, int CH, bool LDSST, int TB = 1024, bool SPEC = false>
 __global__ __launch_bounds__(TB) void k_sap(int n, int nchunks, const ShardTab tab,
                                               typename Tr<CT>::PT *__restrict__ pk, int *__restrict__ owner_g,
                                               int *__restrict__ r2c, int *__restrict__ pred_g, int *__restrict__ list,
-                                              int *__restrict__ ctl)
+                                              int *__restrict__ ctl, PsRec<typename Tr<CT>::PT> *__restrict__ recs = nullptr)
 {
     using PT = typename Tr<CT>::PT;
     constexpr int E = Tr<CT>::E;
@@ -983,6 +1000,7 @@ __global__ __launch_bounds__(TB) void k_sap(int n, int nchunks, const ShardTab t
     constexpr bool PREG = (NV * (int)sizeof(PT) / 4) <= 32;  // cache own prices / owners in registers
     constexpr PT KMAX = Tr<CT>::KMAX;
     static_assert(NV <= 64, "scanned mask is 64 bits");
+    static_assert(!SPEC || (PREG && LDSST), "speculative searches keep prices in registers and owner/pred in LDS");
     // LDS: owner[] and pred[] (random access by the path walk and the argmin winner).  Prices
     // stay in registers during a search (global memory between searches), and NO global store
     // happens inside the step loop: a __syncthreads() drains vmcnt, so a store there would put
@@ -998,6 +1016,7 @@ __global__ __launch_bounds__(TB) void k_sap(int n, int nchunks, const ShardTab t
     __shared__ int s_wcnt[16];
 
     if (ctl[CTL_FLAG]) return;
+    if (SPEC && (ctl[CTL_PSTOP] || (int)blockIdx.x >= ctl[CTL_NFREE])) return;
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
     const int npad = nchunks * E;
     const size_t pitch = (size_t)npad;
@@ -1006,7 +1025,7 @@ __global__ __launch_bounds__(TB) void k_sap(int n, int nchunks, const ShardTab t
     int *PRED = LDSST ? reinterpret_cast<int *>(smem + (size_t)npad * sizeof(int)) : pred_g;
 
     for (int j = tid; j < npad; j += T) {
-        P[j] = pk[j] >> 1;
+        if (!SPEC) P[j] = pk[j] >> 1;
         if (LDSST) OWN[j] = owner_g[j];
     }
     // the ordered list of free rows was built by k_freelist / the last k_pcommit
@@ -1037,11 +1056,19 @@ __global__ __launch_bounds__(TB) void k_sap(int n, int nchunks, const ShardTab t
         for (int q = 0; q < CH; q++) {
             const int ch = q * T + tid;
 #pragma unroll
-            for (int e = 0; e < E; e++) preg[q * E + e] = (ch < nchunks) ? P[ch * E + e] : (PT)0;
+            for (int e = 0; e < E; e++)
+                preg[q * E + e] = (ch < nchunks) ? (SPEC ? (PT)(pk[ch * E + e] >> 1) : P[ch * E + e]) : (PT)0;
         }
     }
     // software prefetch of the NEXT free row (its id and its 16-byte chunks) behind the current search
-    int fnext = nfree > 0 ? list[0] : 0;
+    // SPEC: the searches of a batch are spread evenly over the (row-ordered) free list: neighbouring
+    // rows tend to want the same columns (cabs at one stand) and would only reject each other
+    const int gact = nfree < (int)gridDim.x ? nfree : (int)gridDim.x;
+    int fnext = nfree > 0 ? list[SPEC ? (int)(((long long)blockIdx.x * nfree) / gact) : 0] : 0;
+    // SPEC: ties (equal distance, same owned bit) are broken by a column order rotated per search:
+    // with the plain lowest-index rule every search of a batch would end in the same free column
+    // of a tie class and all but one would be rejected
+    const int rot = SPEC ? (int)(((uint64_t)(((uint32_t)fnext + 1u) * 0x9E3779B1u) * (uint64_t)npad) >> 32) : 0;
     uint4 cvn[CH];
     if (nfree > 0) {
         const CT *nrow = shard_row<CT>(tab, fnext, pitch);
@@ -1051,12 +1078,12 @@ __global__ __launch_bounds__(TB) void k_sap(int n, int nchunks, const ShardTab t
             if (ch < nchunks) cvn[q] = *reinterpret_cast<const uint4 *>(nrow + (size_t)ch * E);
         }
     }
-    for (int fi = 0; fi < nfree && !bad; fi++) {
+    for (int fi = 0; fi < (SPEC ? 1 : nfree) && !bad; fi++) {
         const int f = fnext;
         uint4 cvf[CH];
 #pragma unroll
         for (int q = 0; q < CH; q++) cvf[q] = cvn[q];
-        if (fi + 1 < nfree) {
+        if (!SPEC && fi + 1 < nfree) {
             fnext = list[fi + 1];
             const CT *nrow = shard_row<CT>(tab, fnext, pitch);
 #pragma unroll
@@ -1113,9 +1140,11 @@ __global__ __launch_bounds__(TB) void k_sap(int n, int nchunks, const ShardTab t
                 for (int e = 0; e < E; e++) {
                     const bool ok = !((scanned >> (q * E + e)) & 1ull);
                     const PT v = (PT)(d[q * E + e] << 1) | (PT)((ownedmask >> (q * E + e)) & 1ull);
-                    if (ok && v < bk) {
+                    int jr = (q * T + tid) * E + e - rot;   // rotated index while reducing (SPEC)
+                    jr += (jr < 0) ? npad : 0;
+                    if (ok && (v < bk || (SPEC && v == bk && jr < bj))) {
                         bk = v;
-                        bj = (q * T + tid) * E + e;
+                        bj = jr;
                         if (PREG) {
                             bo = ownr[q * E + e];
                             bp = preg[q * E + e];
@@ -1144,11 +1173,55 @@ __global__ __launch_bounds__(TB) void k_sap(int n, int nchunks, const ShardTab t
                 bad = true;
                 break;
             }
+            bj += rot;  // back to the column index
+            bj -= (bj >= npad) ? npad : 0;
             const bool col_owned = (bk & 1) != 0;
             const PT bd = bk >> 1;  // the distance
             if (!col_owned) {      // free column reached
                 mind = bd;
                 endcol = bj;
+                if (SPEC) {
+                    // Usually a whole class of free columns is tied at the end distance (dummy
+                    // columns of a simulator model): take the k-th of them, k spread over the
+                    // searches of the batch, so that concurrent searches end in DIFFERENT columns
+                    // instead of rejecting each other at commit.
+                    unsigned long long tiemask = 0ull;
+#pragma unroll
+                    for (int k = 0; k < NV; k++) {
+                        const bool tie = !((scanned >> k) & 1ull) && !((ownedmask >> k) & 1ull) && d[k] == bd;
+                        tiemask |= tie ? (1ull << k) : 0ull;
+                    }
+                    const int mycnt = __popcll(tiemask);
+                    int incl = mycnt;
+#pragma unroll
+                    for (int sh = 1; sh < 64; sh <<= 1) {
+                        const int v = __shfl_up(incl, sh);
+                        if (lane >= sh) incl += v;
+                    }
+                    if (lane == 63) s_wcnt[w] = incl;
+                    __syncthreads();
+                    int base = 0, total = 0;
+                    for (int q = 0; q < nw; q++) {
+                        const int cw = s_wcnt[q];
+                        base += (q < w) ? cw : 0;
+                        total += cw;
+                    }
+                    const int target = (int)(((uint64_t)(((uint32_t)blockIdx.x + 1u) * 0x9E3779B1u) * (uint64_t)total) >> 32);
+                    const int lo = base + incl - mycnt;
+                    if (target >= lo && target < lo + mycnt) {
+                        int skip = target - lo;
+#pragma unroll
+                        for (int k = 0; k < NV; k++) {
+                            if ((tiemask >> k) & 1ull) {
+                                if (skip == 0) s_bcol[0] = ((k / E) * T + tid) * E + (k % E);
+                                skip--;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    if (total > 0) endcol = s_bcol[0];
+                    __syncthreads();
+                }
                 break;
             }
             const int o = PREG ? bo : OWN[bj];
@@ -1275,6 +1348,63 @@ __global__ __launch_bounds__(TB) void k_sap(int n, int nchunks, const ShardTab t
                 }
             }
         }
+        if (SPEC) {
+            // record: the columns whose label is final and below the end distance (exactly the set
+            // the dual update would touch), the end column, the path
+            PsRec<PT> *rec = recs + blockIdx.x;
+            unsigned long long fin = 0ull;
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                const bool in = ((scanned >> k) & 1ull) && !((padmask >> k) & 1ull) && d[k] < mind;
+                fin |= in ? (1ull << k) : 0ull;
+            }
+            const int mycnt = (endcol >= 0) ? __popcll(fin) : 0;
+            int incl = mycnt;
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) {
+                const int v = __shfl_up(incl, sh);
+                if (lane >= sh) incl += v;
+            }
+            __syncthreads();
+            if (lane == 63) s_wcnt[w] = incl;
+            __syncthreads();
+            int base = 0, total = 0;
+            for (int q = 0; q < nw; q++) {
+                const int cw = s_wcnt[q];
+                base += (q < w) ? cw : 0;
+                total += cw;
+            }
+            const bool fits = endcol >= 0 && total <= PS_CAP;
+            if (fits) {
+                int pos = base + incl - mycnt;
+#pragma unroll
+                for (int k = 0; k < NV; k++) {
+                    if ((fin >> k) & 1ull) {
+                        rec->S_col[pos] = ((k / E) * T + tid) * E + (k % E);
+                        rec->S_d[pos] = d[k];
+                        pos++;
+                    }
+                }
+            }
+            if (tid == 0) {
+                int status = fits ? 1 : 0, plen = 0;
+                if (status) {
+                    int jc = endcol;
+                    while (jc >= 0 && plen <= PS_CAP) {
+                        rec->path[plen++] = jc;
+                        jc = PRED[jc];
+                    }
+                    if (jc >= 0) status = 0;
+                }
+                rec->f = f;
+                rec->endcol = endcol;
+                rec->nS = fits ? total : 0;
+                rec->plen = plen;
+                rec->mind = mind;
+                rec->status = status;
+            }
+            return;
+        }
         if (endcol < 0) {
             bad = true;
             break;
@@ -1344,19 +1474,6 @@ __global__ __launch_bounds__(TB) void k_sap(int n, int nchunks, const ShardTab t
 // =====================================================================================
 constexpr int SAP_W = 16;  // columns of one tie class finalised per step
 constexpr int SAP_G = 4;   // rows streamed per load group
-
-constexpr int PS_G = 192;     // searches per batch
-constexpr int PS_CAP = 4096;  // finalised columns recorded per search; longer searches are left to the serial finisher
-
-template <typename PT>
-struct PsRec {
-    int f, endcol, nS, plen, status;  // status 1 = usable
-    int pad[3];
-    PT mind;
-    int S_col[PS_CAP];
-    PT S_d[PS_CAP];
-    int path[PS_CAP + 2];
-};
 
 // SPEC = false: the serial finisher (applies every augmentation itself).
 // SPEC = true : one speculative search per workgroup against a read-only snapshot; the search is
@@ -1655,225 +1772,6 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
 // Results do not depend on workgroup timing: searches of a batch share one snapshot and the
 // claim is a min over ids.
 // =====================================================================================
-template <typename CT, int CH, bool LDSST>
-__global__ __launch_bounds__(1024) void k_psearch(int n, int nchunks, const ShardTab tab,
-                                                  const typename Tr<CT>::PT *__restrict__ pk,
-                                                  const int *__restrict__ owner_g, int *__restrict__ pred_g,
-                                                  const int *__restrict__ list, const int *__restrict__ ctl,
-                                                  PsRec<typename Tr<CT>::PT> *__restrict__ recs)
-{
-    using PT = typename Tr<CT>::PT;
-    constexpr int E = Tr<CT>::E;
-    constexpr int NV = CH * E;   // columns per thread: chunk q*T + tid, q = 0..CH-1 (as k_sap)
-    static_assert(NV <= 32, "column masks are 32 bits");
-    // owners ride along in registers only while they fit (128 VGPRs at 1024 threads); otherwise the
-    // winner's owner is one LDS read after the argmin
-    constexpr bool OREG = (NV * (int)sizeof(PT) / 4) <= 16 || !LDSST;
-    constexpr PT KMAX = Tr<CT>::KMAX;
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ PT s_rk[2][16];
-    __shared__ PT s_rp[2][16];
-    __shared__ int s_rj[2][16];
-    __shared__ int s_ro[2][16];
-    const int nfree = ctl[CTL_NFREE];
-    const int b = blockIdx.x;
-    if (b >= nfree) return;
-    const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
-    const int npad = nchunks * E;
-    const size_t pitch = (size_t)npad;
-    int *OWN = LDSST ? reinterpret_cast<int *>(smem) : nullptr;
-    int *PRED = LDSST ? reinterpret_cast<int *>(smem + (size_t)npad * sizeof(int)) : pred_g + (size_t)b * npad;
-    PsRec<PT> *rec = recs + b;
-    // searches of a batch are spread evenly over the (row-ordered) free list: neighbouring rows
-    // tend to want the same columns (cabs at one stand) and would only reject each other
-    const int gact = nfree < (int)gridDim.x ? nfree : (int)gridDim.x;
-    const int f = list[(int)(((long long)b * nfree) / gact)];
-    // Ties (equal distance, same owned bit) are broken by a column order rotated per search:
-    // with the plain lowest-index rule every search of a batch would end in the same free
-    // column of a tie class and all but one would be rejected.
-    const int rot = (int)(((uint64_t)(((uint32_t)f + 1u) * 0x9E3779B1u) * (uint64_t)npad) >> 32);
-    if (LDSST) {
-        for (int j = tid; j < npad; j += T) OWN[j] = owner_g[j];
-        __syncthreads();
-    }
-    PT d[NV], preg[NV];
-    int ownr[OREG ? NV : 1];
-    uint32_t scanned = 0, owned = 0, valid = 0;
-    {
-        const CT *frow = shard_row<CT>(tab, f, pitch);
-#pragma unroll
-        for (int q = 0; q < CH; q++) {
-            const int ch = q * T + tid;
-            const bool has = ch < nchunks;
-            uint32_t c[E];
-            if (has) {
-                const uint4 cv = *reinterpret_cast<const uint4 *>(frow + (size_t)ch * E);
-                unpack<CT>(cv, c);
-            }
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                const int j = ch * E + e;
-                const bool ok = has && j < n;
-                const PT p = ok ? (PT)(pk[j] >> 1) : (PT)0;
-                const int o = ok ? (LDSST ? OWN[j] : owner_g[j]) : -2;
-                preg[q * E + e] = p;
-                if (OREG) ownr[q * E + e] = o;
-                d[q * E + e] = ok ? (PT)c[e] + p : (KMAX >> 2);
-                if (ok) {
-                    valid |= 1u << (q * E + e);
-                    PRED[j] = -1;
-                }
-                if (o != -1) owned |= 1u << (q * E + e);
-            }
-        }
-    }
-    int steps = 0, par = 0, endcol = -1, status = 1;
-    PT mind = 0;
-    for (int guard = 0; guard <= npad; guard++) {
-        PT bk = KMAX, bp = 0;
-        int bj = INT_MAX, bo = -2;
-#pragma unroll
-        for (int q = 0; q < CH; q++) {
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                const int k = q * E + e;
-                const bool ok = ((valid >> k) & 1u) && !((scanned >> k) & 1u);
-                const PT v = (PT)(d[k] << 1) | (PT)((owned >> k) & 1u);
-                int jr = (q * T + tid) * E + e - rot;
-                jr += (jr < 0) ? npad : 0;
-                if (ok && (v < bk || (v == bk && jr < bj))) {
-                    bk = v;
-                    bj = jr;  // rotated index while reducing
-                    if (OREG) bo = ownr[k];
-                    bp = preg[k];
-                }
-            }
-        }
-        wave_argmin<PT>(bk, bj, bo, bp);
-        if (nw > 1) {
-            if (lane == 0) {
-                s_rk[par][w] = bk;
-                s_rj[par][w] = bj;
-                s_ro[par][w] = bo;
-                s_rp[par][w] = bp;
-            }
-            __syncthreads();
-            const bool hv = lane < nw;
-            bk = hv ? s_rk[par][lane] : KMAX;
-            bj = hv ? s_rj[par][lane] : INT_MAX;
-            bo = hv ? s_ro[par][lane] : -2;
-            bp = hv ? s_rp[par][lane] : (PT)0;
-            wave_argmin<PT>(bk, bj, bo, bp);
-            par ^= 1;
-        }
-        if (bj == INT_MAX) {
-            status = 0;
-            break;
-        }
-        bj += rot;  // back to the column index
-        bj -= (bj >= npad) ? npad : 0;
-        if (!OREG) bo = OWN[bj];
-        const PT bd = bk >> 1;
-        if (!(bk & 1)) {
-            // A free column is at the frontier distance.  Usually a whole class of free columns
-            // is tied there (dummy columns of a simulator model): take the k-th of them, k spread
-            // over the searches of the batch, so that concurrent searches end in DIFFERENT columns
-            // instead of rejecting each other at commit.
-            uint32_t tiemask = 0;
-#pragma unroll
-            for (int k = 0; k < NV; k++) {
-                const bool tie = ((valid >> k) & 1u) && !((scanned >> k) & 1u) && !((owned >> k) & 1u) && d[k] == bd;
-                tiemask |= tie ? (1u << k) : 0u;
-            }
-            const int mycnt = __popc(tiemask);
-            int incl = mycnt;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int v = __shfl_up(incl, o);
-                if (lane >= o) incl += v;
-            }
-            if (lane == 63) s_ro[par][w] = incl;   // reuse the exchange slots
-            __syncthreads();
-            int base = 0, total = 0;
-            for (int q = 0; q < nw; q++) {
-                const int cw = s_ro[par][q];
-                base += (q < w) ? cw : 0;
-                total += cw;
-            }
-            const int target = (int)(((uint64_t)(((uint32_t)b + 1u) * 0x9E3779B1u) * (uint64_t)total) >> 32);
-            const int lo = base + incl - mycnt;
-            if (target >= lo && target < lo + mycnt) {
-                int skip = target - lo;
-#pragma unroll
-                for (int k = 0; k < NV; k++) {
-                    if ((tiemask >> k) & 1u) {
-                        if (skip == 0) s_rj[par ^ 1][0] = ((k / E) * T + tid) * E + (k % E);
-                        skip--;
-                    }
-                }
-            }
-            __syncthreads();
-            mind = bd;
-            endcol = (total > 0) ? s_rj[par ^ 1][0] : bj;
-            par ^= 1;
-            break;
-        }
-        if (steps >= PS_CAP) {  // too long for a speculative record
-            status = 0;
-            break;
-        }
-        if (tid == 0) {
-            rec->S_col[steps] = bj;
-            rec->S_d[steps] = bd;
-        }
-        steps++;
-        {
-            const int chq = bj / E;
-            if ((chq % T) == tid) scanned |= 1u << ((chq / T) * E + (bj - chq * E));
-        }
-        const CT *rp = shard_row<CT>(tab, bo, pitch);
-        const PT wstar = (PT)rp[bj] + bp;
-#pragma unroll
-        for (int q = 0; q < CH; q++) {
-            const int ch = q * T + tid;
-            if (ch < nchunks) {
-                const uint4 cv = *reinterpret_cast<const uint4 *>(rp + (size_t)ch * E);
-                uint32_t c[E];
-                unpack<CT>(cv, c);
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    const int k = q * E + e;
-                    const PT h = bd + ((PT)c[e] + preg[k] - wstar);
-                    const bool ok = ((valid >> k) & 1u) && !((scanned >> k) & 1u);
-                    if (ok && h < d[k]) {
-                        d[k] = h;
-                        PRED[ch * E + e] = bj;  // predecessor COLUMN (the path walk then needs no row->col map)
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int plen = 0;
-        if (status == 1 && endcol >= 0) {
-            int j = endcol;
-            while (j >= 0 && plen <= PS_CAP) {
-                rec->path[plen++] = j;
-                j = PRED[j];
-            }
-            if (j >= 0) status = 0;
-        } else
-            status = 0;
-        rec->f = f;
-        rec->endcol = endcol;
-        rec->nS = steps;
-        rec->plen = plen;
-        rec->mind = mind;
-        rec->status = status;
-    }
-}
-
 // commit of one batch + rebuild of the ordered free-row list.  One workgroup.
 //
 // Acceptance (deterministic, order = search id r):
@@ -1968,8 +1866,10 @@ __global__ __launch_bounds__(1024) void k_pcommit(int n, PT *__restrict__ pk, in
     if (tid == 0) s_nfree = nleft;
     __syncthreads();
     if (tid == 0) {
-        // nothing accepted (every search overflowed): stop launching useful work for later batches
-        ctl[CTL_NFREE] = (!first && s_acc == 0) ? 0 : s_nfree;
+        // nothing accepted (every search overflowed its record): later batches of this group exit
+        // at once; the rows stay in the list for the serial finisher
+        ctl[CTL_NFREE] = s_nfree;
+        if (!first && s_acc == 0) ctl[CTL_PSTOP] = 1;
         ctl[CTL_PACC] += s_acc;
     }
 }
@@ -2298,19 +2198,25 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
         if (cshm > 48 * 1024)
             (void)hipFuncSetAttribute((const void *)k_pcommit<PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cshm);
         unsigned long long *raise = (unsigned long long *)sv.bid.p;  // all zero after the bidding rounds
+        // the speculative search is the finisher kernel itself in SPEC mode (same batched steps)
+        const bool tb512 = g_sap512 && T <= 512;
         auto search = [&]() {
-#define TD_PS(CHV)                                                                                                         \
+#define TD_PS(CHV, TBV)                                                                                                    \
     if constexpr (CHV * E <= 16) {                                                                                         \
         if (shm > 48 * 1024)                                                                                               \
-            (void)hipFuncSetAttribute((const void *)k_psearch<CT, CHV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)shm);                                                                           \
-        k_psearch<CT, CHV, true><<<PS_G, T, shm, c.stream>>>(n, nchunks, tab, (const PT *)sv.price.p,                     \
-                                                            (const int *)sv.owner.p, (int *)sv.pred.p,                     \
-                                                            (const int *)sv.list.p, (const int *)sv.misc.p, recs);         \
+            (void)hipFuncSetAttribute((const void *)k_sap<CT, CHV, true, TBV, true>,                                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                               \
+        k_sap<CT, CHV, true, TBV, true><<<PS_G, T, shm, c.stream>>>(n, nchunks, tab, (PT *)sv.price.p, (int *)sv.owner.p,  \
+                                                                   r2c_full, (int *)sv.pred.p, (int *)sv.list.p,           \
+                                                                   (int *)sv.misc.p, recs);                                \
     }
-            if (CH == 1) { TD_PS(1) }
-            else if (CH == 2) { TD_PS(2) }
-            else { TD_PS(4) }
+            if (CH == 1) {
+                if (tb512) { TD_PS(1, 512) } else { TD_PS(1, 1024) }
+            } else if (CH == 2) {
+                if (tb512) { TD_PS(2, 512) } else { TD_PS(2, 1024) }
+            } else {
+                if (tb512) { TD_PS(4, 512) } else { TD_PS(4, 1024) }
+            }
 #undef TD_PS
         };
         // Batches go out in groups; one small read-back of the free-row count per group decides
