@@ -11,9 +11,19 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 120
 cnt = bad = 0
 while time.time() < t_end:
-    kind = ["g1", "g4", "g2", "g3", "wide", "neg", "const"][int(rng.integers(0, 7))]
+    kind = ["g1", "g4", "g2", "g3", "wide", "neg", "const", "rect"][int(rng.integers(0, 8))]
     n = int(rng.integers(2, 1400)) if kind not in ("g2", "wide") else int(rng.integers(2, 700))
-    c = make_instance(kind, n, rng)
+    if kind == "rect":   # padded rectangular model: constant rows / columns, sometimes permuted
+        rr, rc = int(rng.integers(1, n + 1)), int(rng.integers(1, n + 1))
+        c = np.full((n, n), 250000, np.int32)
+        blk = rng.integers(0, int(rng.choice([10, 50, 100000])), (rr, rc)).astype(np.int32)
+        if rng.random() < 0.5:
+            blk[rng.random(blk.shape) < 0.7] = 250000
+        c[:rr, :rc] = blk
+        if rng.random() < 0.3:
+            c = np.ascontiguousarray(c[rng.permutation(n)][:, rng.permutation(n)])
+    else:
+        c = make_instance(kind, n, rng)
     r2c, tot, dual = td.assign(c, want_dual=True)
     ref = oracle.assign(c)[0]
     ok = tot == ref == dual and sorted(r2c.tolist()) == list(range(n)) and int(c[np.arange(n), r2c].astype(np.int64).sum()) == tot
