@@ -106,6 +106,8 @@ int g_psap8_grid = 64;      // TD_PSAP8_GRID    searches per such batch
 int g_psap_batches = 16;    // TD_PSAP          speculative batches per group of the generic search (u16 / u32 rows)
 int g_psap_min = 12;        // TD_PSAP_MIN      free rows below which the generic batches are skipped
 int g_psap_cap = 4096;      // TD_PSAP_CAP      total speculative batches per solve
+int g_sapx = 1;             // TD_SAPX          cooperative multi-workgroup serial finisher (k_sapx)
+int g_sapx_min = 8;         // TD_SAPX_MIN      fewest workgroups (256 chunks each) for which it is used
 int g_sap512 = 1;           // TD_SAP512        512-thread generic finisher (double register budget) for n <= 8192
 int g_psap_worth = 4;       // TD_PSAP_WORTH    rows a batch must commit on average for another group to be launched
 int g_psap_u8 = 0;          // TD_PSAP_U8       generic batches for u8 rows too (slower than the lean path)
@@ -132,6 +134,8 @@ void read_tunables()
     if (const char *e = getenv("TD_PSAP_MIN")) g_psap_min = std::max(1, atoi(e));
     if (const char *e = getenv("TD_PSAP_CAP")) g_psap_cap = std::max(0, atoi(e));
     if (const char *e = getenv("TD_SAP512")) g_sap512 = atoi(e) != 0;
+    if (const char *e = getenv("TD_SAPX")) g_sapx = atoi(e) != 0;
+    if (const char *e = getenv("TD_SAPX_MIN")) g_sapx_min = std::max(1, atoi(e));
     if (const char *e = getenv("TD_PSAP_WORTH")) g_psap_worth = std::max(1, atoi(e));
     if (const char *e = getenv("TD_PSAP_U8")) g_psap_u8 = atoi(e) != 0;
     if (const char *e = getenv("TD_SPECULATE")) g_speculate = atoi(e) != 0;
@@ -1462,6 +1466,369 @@ __global__ __launch_bounds__(TB) void k_sap(int n, int nchunks, const ShardTab t
 }
 
 // =====================================================================================
+// k_sapx: the serial finisher spread over K workgroups (one search at a time, columns split).
+//
+// One workgroup cannot stream rows faster than one CU's load path: at N = 16 384 a batched step of
+// k_sap moves 1 MiB through a single CU (~38 us). Here workgroup g owns the column chunks
+// [g*T, (g+1)*T); every step each workgroup publishes up to SX_WL of its open owned columns (its
+// local minimum first, then the ones inside the window above the last global minimum), ONE grid
+// barrier, then every workgroup relaxes ITS columns against all published rows. The search is the
+// same label-correcting scheme as k_sap (any scan order is valid; a column whose label drops is
+// re-opened), it ends when no workgroup has an open owned column below the smallest free-column
+// label — plain Dijkstra termination, so labels below the end distance are exact.
+// The barrier is a monotonic 64-bit counter in global memory, release/acquire at agent scope,
+// with a spin limit: a workgroup that waits too long raises `abort`, every workgroup leaves and
+// the host reports TD_EINTERNAL (no unbounded spin). K <= 64 workgroups of <= 256 threads are
+// always co-resident on the 256 CUs (the stream is serial: nothing else runs).
+// =====================================================================================
+constexpr int SX_WL = 8;       // columns a workgroup may publish per step
+constexpr int SX_KMAX = 64;    // workgroups
+#ifndef TD_SX_G
+#define TD_SX_G 8
+#endif
+constexpr int SX_G = TD_SX_G;  // rows in flight per relax group
+struct SxSlot {
+    long long flabel;   // smallest label among this workgroup's free columns
+    int fcol;
+    int cnt;            // published entries
+};
+struct SxEnt {
+    long long d, p;
+    int col, own;
+};
+struct SxShared {
+    unsigned long long bar;
+    int abort;
+    int pad;
+    long long dbg[4];   // cycles of workgroup 0: barrier wait, selection, publish read, relax (TD_DEBUG)
+    SxSlot slot[2][SX_KMAX];
+    SxEnt ent[2][SX_KMAX][SX_WL];
+};
+
+template <typename CT, int TX>
+__global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab tab, typename Tr<CT>::PT *__restrict__ pk,
+                                             int *owner_g, int *__restrict__ r2c, int *pred_g,
+                                             const int *__restrict__ list, int *__restrict__ ctl, SxShared *sh)
+{
+    using PT = typename Tr<CT>::PT;
+    typedef long long LT;
+    constexpr int E = Tr<CT>::E;
+    constexpr int NW = TX / 64;
+    constexpr LT LMAX = (LT)1 << 62;
+    __shared__ LT s_k[NW], s_p[NW], s_f[NW];
+    __shared__ int s_j[NW], s_o[NW], s_fj[NW], s_wcnt[NW];
+    __shared__ SxSlot s_slot[SX_KMAX];
+    // per published column, computed once per workgroup: label minus the owner's row dual, the
+    // owner's row (this workgroup's segment), the column
+    __shared__ LT s_bs[SX_KMAX * SX_WL];
+    __shared__ const CT *s_rp[SX_KMAX * SX_WL];
+    __shared__ int s_ce[SX_KMAX * SX_WL];
+    __shared__ int s_ok;
+    if (ctl[CTL_FLAG]) return;
+    const int nfree = ctl[CTL_NFREE];
+    if (nfree <= 0) return;
+    const int K = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int npad = nchunks * E;
+    const size_t pitch = (size_t)npad;
+    const int ch = wg * TX + tid;
+    const bool has = ch < nchunks;
+    const int jbase = ch * E;
+    uint32_t valid = 0;
+    LT preg[E];
+    int ownr[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const bool ok = has && jbase + e < n;
+        valid |= ok ? (1u << e) : 0u;
+        preg[e] = has ? (LT)(pk[jbase + e] >> 1) : 0;   // pad columns keep their (huge) price
+        ownr[e] = ok ? owner_g[jbase + e] : -2;
+    }
+    unsigned long long epoch = 0;
+    // grid barrier; false = some workgroup gave up (abort raised)
+    auto grid_sync = [&]() -> bool {
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            atomicAdd(&sh->bar, 1ull);
+            const unsigned long long target = (epoch + 1ull) * (unsigned long long)K;
+            int ok = 1;
+            for (long long spins = 0;; spins++) {
+                if (__hip_atomic_load(&sh->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+                if (spins > 2000000ll || __hip_atomic_load(&sh->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(&sh->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_ok = ok;
+        }
+        epoch++;
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        return s_ok != 0;
+    };
+    long long steps = 0;
+    LT delta = 0;
+    bool bad = false;
+    for (int fi = 0; fi < nfree && !bad; fi++) {
+        const int f = list[fi];
+        LT d[E], dp[E];
+        uint32_t scanned = ~valid, owned = ~valid;
+        {
+            uint32_t c[E];
+            if (has) {
+                const uint4 cv = *reinterpret_cast<const uint4 *>(shard_row<CT>(tab, f, pitch) + (size_t)jbase);
+                unpack<CT>(cv, c);
+            }
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const bool ok = (valid >> e) & 1u;
+                d[e] = ok ? (LT)c[e] + preg[e] : LMAX;
+                dp[e] = ok ? (LT)c[e] : -LMAX;
+                if (ok) pred_g[jbase + e] = -1;
+                if (ownr[e] != -1) owned |= 1u << e;
+            }
+        }
+        LT F = LMAX, base = LMAX, mind = 0;   // stale global values from the last barrier
+        int endcol = -1, par = 0;
+        bool first = true, done = false;
+        for (int guard = 0; guard <= npad + 8 && !done; guard++) {
+            const long long tc0 = clock64();
+            // ---- local selection: smallest open owned column below F, smallest free label
+            LT bk = LMAX, bp = 0, fk = LMAX;
+            int bj = INT_MAX, bo = -2, fj = INT_MAX;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const bool open = !((scanned >> e) & 1u);
+                const bool ow = (owned >> e) & 1u;
+                if (open && ow && d[e] < F && d[e] < bk) {
+                    bk = d[e];
+                    bj = jbase + e;
+                    bo = ownr[e];
+                    bp = preg[e];
+                }
+                if (((valid >> e) & 1u) && !ow && d[e] < fk) {
+                    fk = d[e];
+                    fj = jbase + e;
+                }
+            }
+            wave_argmin<LT>(bk, bj, bo, bp);
+            {
+                int o2 = 0;
+                LT p2 = 0;
+                wave_argmin<LT>(fk, fj, o2, p2);
+            }
+            if (lane == 0) {
+                s_k[w] = bk;
+                s_j[w] = bj;
+                s_o[w] = bo;
+                s_p[w] = bp;
+                s_f[w] = fk;
+                s_fj[w] = fj;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                if (s_k[q] < bk || (s_k[q] == bk && s_j[q] < bj)) {
+                    bk = s_k[q];
+                    bj = s_j[q];
+                    bo = s_o[q];
+                    bp = s_p[q];
+                }
+                if (s_f[q] < fk || (s_f[q] == fk && s_fj[q] < fj)) {
+                    fk = s_f[q];
+                    fj = s_fj[q];
+                }
+            }
+            // candidates besides the local minimum: open owned columns below F inside the window
+            uint32_t cand = 0;
+            const LT lim = (first || base >= LMAX - delta) ? -1 : base + delta;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const bool ok = !((scanned >> e) & 1u) && ((owned >> e) & 1u) && d[e] < F && d[e] <= lim && (jbase + e) != bj;
+                cand |= ok ? (1u << e) : 0u;
+            }
+            const int mycnt = __popc(cand);
+            int incl = mycnt;
+#pragma unroll
+            for (int shf = 1; shf < 64; shf <<= 1) {
+                const int v = __shfl_up(incl, shf);
+                if (lane >= shf) incl += v;
+            }
+            __syncthreads();   // s_k.. consumed
+            if (lane == 63) s_wcnt[w] = incl;
+            __syncthreads();
+            const int head = (bj != INT_MAX) ? 1 : 0;
+            int pos = head, tot = head;
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                pos += (q < w) ? s_wcnt[q] : 0;
+                tot += s_wcnt[q];
+            }
+            pos += incl - mycnt;
+            SxEnt *ge = sh->ent[par][wg];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if (((cand >> e) & 1u) && pos < SX_WL) {
+                    ge[pos].d = d[e];
+                    ge[pos].p = preg[e];
+                    ge[pos].col = jbase + e;
+                    ge[pos].own = ownr[e];
+                    scanned |= 1u << e;
+                    pos++;
+                }
+            }
+            if (head && bj >= jbase && bj < jbase + E) scanned |= 1u << (bj - jbase);
+            if (tid == 0) {
+                if (head) {
+                    ge[0].d = bk;
+                    ge[0].p = bp;
+                    ge[0].col = bj;
+                    ge[0].own = bo;
+                }
+                SxSlot sl;
+                sl.flabel = fk;
+                sl.fcol = fj;
+                sl.cnt = min(tot, SX_WL);
+                sh->slot[par][wg] = sl;
+            }
+            const long long tc1 = clock64();
+            if (!grid_sync()) {
+                bad = true;
+                break;
+            }
+            const long long tc2 = clock64();
+            // ---- everybody reads the published step
+            if (tid < K) s_slot[tid] = sh->slot[par][tid];
+            __syncthreads();
+            int B = 0;
+            LT nF = LMAX;
+            int nFj = INT_MAX;
+            for (int q = 0; q < K; q++) {
+                const SxSlot sl = s_slot[q];
+                if (sl.flabel < nF || (sl.flabel == nF && sl.fcol < nFj)) {
+                    nF = sl.flabel;
+                    nFj = sl.fcol;
+                }
+                B += sl.cnt;
+            }
+            F = nF;
+            if (B == 0) {   // no open owned column below the smallest free label: Dijkstra is done
+                if (nFj == INT_MAX) bad = true;
+                mind = nF;
+                endcol = nFj;
+                done = true;
+                break;
+            }
+            steps++;
+            LT nbase = LMAX;
+            for (int t = tid; t < K * SX_WL; t += TX) {
+                const int q = t / SX_WL, i = t - q * SX_WL;
+                if (i < s_slot[q].cnt) {
+                    int off = 0;
+                    for (int r = 0; r < q; r++) off += s_slot[r].cnt;
+                    const SxEnt en = sh->ent[par][q][i];
+                    const CT *rp = shard_row<CT>(tab, en.own, pitch);
+                    s_bs[off + i] = en.d - ((LT)rp[en.col] + en.p);   // label minus the owner's row dual
+                    s_rp[off + i] = rp + (size_t)wg * TX * E;
+                    s_ce[off + i] = en.col;
+                    nbase = en.d < nbase ? en.d : nbase;
+                }
+            }
+#pragma unroll
+            for (int shf = 32; shf > 0; shf >>= 1) {
+                const LT o = __shfl_xor(nbase, shf);
+                nbase = o < nbase ? o : nbase;
+            }
+            if (lane == 0) s_k[w] = nbase;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NW; q++) nbase = s_k[q] < nbase ? s_k[q] : nbase;
+            const long long tc3 = clock64();
+            const int lofs = has ? tid * E : 0;
+            for (int e0 = 0; e0 < B; e0 += SX_G) {
+                uint4 cv[SX_G];
+#pragma unroll
+                for (int g = 0; g < SX_G; g++) cv[g] = *reinterpret_cast<const uint4 *>(s_rp[min(e0 + g, B - 1)] + lofs);
+#pragma unroll
+                for (int g = 0; g < SX_G; g++) {
+                    const LT bs = s_bs[min(e0 + g, B - 1)];
+                    uint32_t c[E];
+                    unpack<CT>(cv[g], c);
+                    bool any = false;
+#pragma unroll
+                    for (int x = 0; x < E; x++) any = any || (bs + (LT)c[x] < dp[x]);
+                    if (any) {
+                        const int cg = s_ce[min(e0 + g, B - 1)];
+#pragma unroll
+                        for (int x = 0; x < E; x++) {
+                            const LT t = bs + (LT)c[x];
+                            if (t < dp[x]) {
+                                dp[x] = t;
+                                d[x] = t + preg[x];
+                                pred_g[jbase + x] = cg;
+                                scanned &= ~(1u << x);   // (re)opened
+                            }
+                        }
+                    }
+                }
+            }
+            if (wg == 0 && tid == 0) {
+                const long long tc4 = clock64();
+                sh->dbg[0] += tc2 - tc1;
+                sh->dbg[1] += tc1 - tc0;
+                sh->dbg[2] += tc3 - tc2;
+                sh->dbg[3] += tc4 - tc3;
+            }
+            base = nbase;
+            first = false;
+            // window control: aim at about 4 published columns per workgroup
+            if (B > 4 * K)
+                delta >>= 1;
+            else if (B <= 2 * K)
+                delta = (delta < (LMAX >> 8)) ? delta * 2 + 1 : delta;
+            par ^= 1;
+        }
+        if (bad || !done || endcol < 0) {
+            bad = true;
+            break;
+        }
+        // dual update on columns whose (exact) label is below the end distance
+#pragma unroll
+        for (int e = 0; e < E; e++)
+            if (((scanned >> e) & 1u) && ((valid >> e) & 1u) && d[e] < mind) preg[e] += mind - d[e];
+        if (wg == 0 && tid == 0) {   // flip the path (pred / owner are global; the barrier made them visible)
+            int j = endcol;
+            for (int hop = 0; hop <= n; hop++) {
+                const int pc = pred_g[j];
+                const int i = (pc < 0) ? f : owner_g[pc];
+                owner_g[j] = i;
+                r2c[i] = j;
+                if (pc < 0) break;
+                j = pc;
+            }
+        }
+        if (!grid_sync()) {
+            bad = true;
+            break;
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++)
+            if ((valid >> e) & 1u) ownr[e] = owner_g[jbase + e];
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++)
+        if (has) pk[jbase + e] = (PT)((PT)preg[e] << 1) | (PT)1;
+    if (wg == 0 && tid == 0) {
+        ctl[CTL_NFREE] = nfree;
+        ctl[CTL_STEPS] = (int)(steps > INT_MAX ? INT_MAX : steps);
+        if (bad) atomicOr(&ctl[CTL_ERR], 16);
+    }
+}
+
+// =====================================================================================
 // k_sap8: the finisher specialised for u8 rows / int32 prices with ONE 16-column chunk per
 // thread (n <= 16 384).  Same algorithm as k_sap; the step loop is cut to ~1/3 of the VALU
 // instructions (it is issue-bound: 16 waves share 4 SIMDs):
@@ -1984,11 +2351,11 @@ struct td_shard {
     bool fused_bid0 = false;  // the compress pass already published bidding round 0
     int nchunks = 0, npad = 0;
     const int32_t *d_cost = nullptr;  // nrows x n, device
-    Buf stage, cc, price, owner, r2c, r2c_full, bid, pred, list, rowmin, rconst, misc, psrec, tbuf;
+    Buf stage, cc, price, owner, r2c, r2c_full, bid, pred, list, rowmin, rconst, misc, psrec, tbuf, xbuf;
     bool defer_const = false;  // constant rows sit out the solve and take the left-over columns (td_assign only)
     void free_all()
     {
-        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &rconst, &misc, &psrec, &tbuf};
+        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &rconst, &misc, &psrec, &tbuf, &xbuf};
         for (Buf *b : bs) {
             if (b->p) (void)hipFree(b->p);
             b->p = nullptr;
@@ -2245,6 +2612,31 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
             const bool worth = (nfree - left) >= g_psap_worth * nb;
             nfree = left;
             if (!worth) break;
+        }
+    }
+    {   // cooperative finisher: the columns of one search split over several CUs
+        // 256-thread workgroups measured best (one wavefront per workgroup, K = 64: the publish /
+        // read phases grow faster than the relax shrinks; relax time does not scale with rows in
+        // flight either, which points at translation misses on the scattered 64 KiB rows)
+        const int KX = (nchunks + 255) / 256;
+        const bool lean8 = sizeof(CT) == 1 && CH == 1 && g_sap8;
+        if (g_sapx && !lean8 && KX >= g_sapx_min && KX <= SX_KMAX) {
+            Ctx &c = ctx();
+            using PT = typename Tr<CT>::PT;
+            int rc = ensure(sv.xbuf, sizeof(SxShared));
+            if (rc) return rc;
+            TD_HIP(hipMemsetAsync(sv.xbuf.p, 0, 48, c.stream));   // barrier counter, abort flag, debug cycles
+            k_sapx<CT, 256><<<KX, 256, 0, c.stream>>>(n, nchunks, tab, (PT *)sv.price.p, (int *)sv.owner.p, r2c_full,
+                                                      (int *)sv.pred.p, (const int *)sv.list.p, (int *)sv.misc.p,
+                                                      (SxShared *)sv.xbuf.p);
+            TD_HIP(hipGetLastError());
+            if (getenv("TD_DEBUG")) {
+                long long dbg[6];
+                TD_HIP(hipMemcpyAsync(dbg, sv.xbuf.p, sizeof(dbg), hipMemcpyDeviceToHost, c.stream));
+                TD_HIP(hipStreamSynchronize(c.stream));
+                fprintf(stderr, "[td] k_sapx K=%d cycles: barrier %lld select %lld read %lld relax %lld\n", KX, dbg[2], dbg[3], dbg[4], dbg[5]);
+            }
+            return TD_OK;
         }
     }
     if constexpr (sizeof(CT) == 1) {

@@ -201,6 +201,31 @@ def test_reference_shaped_calculate_cost_and_solve(td):
     assert td.solve(dist, [], [], drop_time=10) == (0, [], 0)
 
 
+def test_cooperative_finisher_large_nontied(td):
+    """n = 8192 with 32-bit rows: the rows the speculative batches leave are finished by k_sapx (one
+    search spread over 8 workgroups, grid barrier per step). |a-b| costs have a closed-form optimum
+    (sorted matching); the wide uniform instance is certified by the LP dual."""
+    import torch
+    n = 8192
+    rng = np.random.default_rng(4)
+    a = rng.integers(0, 10 * n, n).astype(np.int32)
+    b = rng.integers(0, 10 * n, n).astype(np.int32)
+    ct = torch.empty((n, n), dtype=torch.int32, device="cuda")
+    td.cost_build(a, b, None, fill=BIG, threshold=-1, out=ct)
+    r2c, total, dual = td.assign(ct, n, want_dual=True)
+    expected = int(np.abs(np.sort(a.astype(np.int64)) - np.sort(b.astype(np.int64))).sum())
+    assert total == expected == dual
+    r2c = np.asarray(r2c)
+    assert sorted(r2c.tolist()) == list(range(n))
+    assert int(np.abs(a.astype(np.int64) - b.astype(np.int64)[r2c]).sum()) == expected
+    assert td.last_stats()["sap_free_rows"] > 0   # the serial finisher had work to do
+    c = rng.integers(0, 10**6, (n, n)).astype(np.int32)
+    r2c, total, dual = td.assign(c, n, want_dual=True)
+    r2c = np.asarray(r2c)
+    assert total == dual and sorted(r2c.tolist()) == list(range(n))
+    assert int(c[np.arange(n), r2c].astype(np.int64).sum()) == total
+
+
 def test_rectangular_models_constant_rows_and_columns(td):
     """Padded rectangular models (solver.py pads to a square with big_cost; Simulator.java:244-252):
     constant rows are deferred, many constant columns switch td_assign to the transposed
