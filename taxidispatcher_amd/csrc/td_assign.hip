@@ -1500,7 +1500,7 @@ struct SxShared {
     unsigned long long bar;
     int abort;
     int pad;
-    long long dbg[4];   // cycles of workgroup 0: barrier wait, selection, publish read, relax (TD_DEBUG)
+    long long dbg[6];   // workgroup 0: cycles in barrier wait, selection, publish read, relax; rows published; steps (TD_DEBUG)
     SxSlot slot[2][SX_KMAX];
     SxEnt ent[2][SX_KMAX][SX_WL];
 };
@@ -1748,10 +1748,25 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
             for (int q = 0; q < NW; q++) nbase = s_k[q] < nbase ? s_k[q] : nbase;
             const long long tc3 = clock64();
             const int lofs = has ? tid * E : 0;
+            // The row pointers come out of LDS, which would make these generic (flat) loads: flat
+            // loads also count on lgkmcnt, so every later LDS read would wait for all of them.
+            // Casting to the global address space keeps them on vmcnt alone, and the loads of the
+            // next group are issued before the current group is relaxed (double buffer).
+            typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+            typedef const v4u_t __attribute__((address_space(1))) *gvec_t;
+            v4u_t cvn[SX_G];
+#pragma unroll
+            for (int g = 0; g < SX_G; g++)
+                cvn[g] = *(gvec_t)(uintptr_t)(s_rp[min(g, B - 1)] + lofs);
             for (int e0 = 0; e0 < B; e0 += SX_G) {
                 uint4 cv[SX_G];
 #pragma unroll
-                for (int g = 0; g < SX_G; g++) cv[g] = *reinterpret_cast<const uint4 *>(s_rp[min(e0 + g, B - 1)] + lofs);
+                for (int g = 0; g < SX_G; g++) cv[g] = make_uint4(cvn[g].x, cvn[g].y, cvn[g].z, cvn[g].w);
+                if (e0 + SX_G < B) {
+#pragma unroll
+                    for (int g = 0; g < SX_G; g++)
+                        cvn[g] = *(gvec_t)(uintptr_t)(s_rp[min(e0 + SX_G + g, B - 1)] + lofs);
+                }
 #pragma unroll
                 for (int g = 0; g < SX_G; g++) {
                     const LT bs = s_bs[min(e0 + g, B - 1)];
@@ -1781,6 +1796,8 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
                 sh->dbg[1] += tc1 - tc0;
                 sh->dbg[2] += tc3 - tc2;
                 sh->dbg[3] += tc4 - tc3;
+                sh->dbg[4] += B;
+                sh->dbg[5] += 1;
             }
             base = nbase;
             first = false;
@@ -2625,16 +2642,17 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
             using PT = typename Tr<CT>::PT;
             int rc = ensure(sv.xbuf, sizeof(SxShared));
             if (rc) return rc;
-            TD_HIP(hipMemsetAsync(sv.xbuf.p, 0, 48, c.stream));   // barrier counter, abort flag, debug cycles
+            TD_HIP(hipMemsetAsync(sv.xbuf.p, 0, 64, c.stream));   // barrier counter, abort flag, debug counters
             k_sapx<CT, 256><<<KX, 256, 0, c.stream>>>(n, nchunks, tab, (PT *)sv.price.p, (int *)sv.owner.p, r2c_full,
                                                       (int *)sv.pred.p, (const int *)sv.list.p, (int *)sv.misc.p,
                                                       (SxShared *)sv.xbuf.p);
             TD_HIP(hipGetLastError());
             if (getenv("TD_DEBUG")) {
-                long long dbg[6];
+                long long dbg[8];
                 TD_HIP(hipMemcpyAsync(dbg, sv.xbuf.p, sizeof(dbg), hipMemcpyDeviceToHost, c.stream));
                 TD_HIP(hipStreamSynchronize(c.stream));
-                fprintf(stderr, "[td] k_sapx K=%d cycles: barrier %lld select %lld read %lld relax %lld\n", KX, dbg[2], dbg[3], dbg[4], dbg[5]);
+                fprintf(stderr, "[td] k_sapx K=%d cycles: barrier %lld select %lld read %lld relax %lld | rows published %lld in %lld steps\n",
+                        KX, dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]);
             }
             return TD_OK;
         }
