@@ -107,6 +107,7 @@ int g_psap_batches = 16;    // TD_PSAP          speculative batches per group of
 int g_psap_min = 12;        // TD_PSAP_MIN      free rows below which the generic batches are skipped
 int g_psap_cap = 4096;      // TD_PSAP_CAP      total speculative batches per solve
 int g_sapx = 1;             // TD_SAPX          cooperative multi-workgroup serial finisher (k_sapx)
+int g_sapx_t = 256;         // TD_SAPX_T        threads per workgroup of k_sapx (64: one wavefront on up to 64 CUs, measured slower)
 int g_sapx_min = 8;         // TD_SAPX_MIN      fewest workgroups (256 chunks each) for which it is used
 int g_sap512 = 1;           // TD_SAP512        512-thread generic finisher (double register budget) for n <= 8192
 int g_psap_worth = 4;       // TD_PSAP_WORTH    rows a batch must commit on average for another group to be launched
@@ -136,6 +137,7 @@ void read_tunables()
     if (const char *e = getenv("TD_SAP512")) g_sap512 = atoi(e) != 0;
     if (const char *e = getenv("TD_SAPX")) g_sapx = atoi(e) != 0;
     if (const char *e = getenv("TD_SAPX_MIN")) g_sapx_min = std::max(1, atoi(e));
+    if (const char *e = getenv("TD_SAPX_T")) g_sapx_t = atoi(e) == 64 ? 64 : 256;
     if (const char *e = getenv("TD_PSAP_WORTH")) g_psap_worth = std::max(1, atoi(e));
     if (const char *e = getenv("TD_PSAP_U8")) g_psap_u8 = atoi(e) != 0;
     if (const char *e = getenv("TD_SPECULATE")) g_speculate = atoi(e) != 0;
@@ -1523,6 +1525,7 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
     __shared__ LT s_bs[SX_KMAX * SX_WL];
     __shared__ const CT *s_rp[SX_KMAX * SX_WL];
     __shared__ int s_ce[SX_KMAX * SX_WL];
+    __shared__ int s_off[64];
     __shared__ int s_ok;
     if (ctl[CTL_FLAG]) return;
     const int nfree = ctl[CTL_NFREE];
@@ -1724,17 +1727,51 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
             }
             steps++;
             LT nbase = LMAX;
-            for (int t = tid; t < K * SX_WL; t += TX) {
-                const int q = t / SX_WL, i = t - q * SX_WL;
-                if (i < s_slot[q].cnt) {
-                    int off = 0;
-                    for (int r = 0; r < q; r++) off += s_slot[r].cnt;
-                    const SxEnt en = sh->ent[par][q][i];
-                    const CT *rp = shard_row<CT>(tab, en.own, pitch);
-                    s_bs[off + i] = en.d - ((LT)rp[en.col] + en.p);   // label minus the owner's row dual
-                    s_rp[off + i] = rp + (size_t)wg * TX * E;
-                    s_ce[off + i] = en.col;
-                    nbase = en.d < nbase ? en.d : nbase;
+            {
+                // offsets of the workgroups' entries in the compact list: one wave scan over the counts
+                if (tid < 64) {
+                    const int cq = (tid < K) ? s_slot[tid].cnt : 0;
+                    int inc = cq;
+#pragma unroll
+                    for (int shf = 1; shf < 64; shf <<= 1) {
+                        const int v = __shfl_up(inc, shf);
+                        if (lane >= shf) inc += v;
+                    }
+                    s_off[tid] = inc - cq;
+                }
+                __syncthreads();
+                // all entry loads of a thread are issued together, then all row-dual loads: two
+                // memory round trips per step however many entries a thread has to fetch
+                constexpr int NIT = (SX_KMAX * SX_WL + TX - 1) / TX;
+                SxEnt en[NIT];
+                bool ok[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const int t = it * TX + tid;
+                    const int q = t / SX_WL, i = t - q * SX_WL;
+                    ok[it] = q < K && i < s_slot[q < K ? q : 0].cnt;
+                    if (ok[it]) en[it] = sh->ent[par][q][i];
+                }
+                CT cw[NIT];
+                const CT *rps[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    if (ok[it]) {
+                        rps[it] = shard_row<CT>(tab, en[it].own, pitch);
+                        cw[it] = rps[it][en[it].col];
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    if (ok[it]) {
+                        const int t = it * TX + tid;
+                        const int q = t / SX_WL, i = t - q * SX_WL;
+                        const int at = s_off[q] + i;
+                        s_bs[at] = en[it].d - ((LT)cw[it] + en[it].p);   // label minus the owner's row dual
+                        s_rp[at] = rps[it] + (size_t)wg * TX * E;
+                        s_ce[at] = en[it].col;
+                        nbase = en[it].d < nbase ? en[it].d : nbase;
+                    }
                 }
             }
 #pragma unroll
@@ -2632,20 +2669,26 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
         }
     }
     {   // cooperative finisher: the columns of one search split over several CUs
-        // 256-thread workgroups measured best (one wavefront per workgroup, K = 64: the publish /
-        // read phases grow faster than the relax shrinks; relax time does not scale with rows in
-        // flight either, which points at translation misses on the scattered 64 KiB rows)
-        const int KX = (nchunks + 255) / 256;
+        // 256-thread workgroups by default. One wavefront per workgroup on up to 64 CUs (TD_SAPX_T=64)
+        // was measured slower: the time per published row does not shrink with the segment a CU
+        // loads (0.15 us either way), while twice as many rows are published per step
+        const int TXsel = (g_sapx_t == 64 && (nchunks + 63) / 64 <= SX_KMAX) ? 64 : 256;
+        const int KX = (nchunks + TXsel - 1) / TXsel;
         const bool lean8 = sizeof(CT) == 1 && CH == 1 && g_sap8;
-        if (g_sapx && !lean8 && KX >= g_sapx_min && KX <= SX_KMAX) {
+        if (g_sapx && !lean8 && KX * TXsel >= g_sapx_min * 256 && KX <= SX_KMAX) {
             Ctx &c = ctx();
             using PT = typename Tr<CT>::PT;
             int rc = ensure(sv.xbuf, sizeof(SxShared));
             if (rc) return rc;
             TD_HIP(hipMemsetAsync(sv.xbuf.p, 0, 64, c.stream));   // barrier counter, abort flag, debug counters
-            k_sapx<CT, 256><<<KX, 256, 0, c.stream>>>(n, nchunks, tab, (PT *)sv.price.p, (int *)sv.owner.p, r2c_full,
-                                                      (int *)sv.pred.p, (const int *)sv.list.p, (int *)sv.misc.p,
-                                                      (SxShared *)sv.xbuf.p);
+            if (TXsel == 64)
+                k_sapx<CT, 64><<<KX, 64, 0, c.stream>>>(n, nchunks, tab, (PT *)sv.price.p, (int *)sv.owner.p, r2c_full,
+                                                        (int *)sv.pred.p, (const int *)sv.list.p, (int *)sv.misc.p,
+                                                        (SxShared *)sv.xbuf.p);
+            else
+                k_sapx<CT, 256><<<KX, 256, 0, c.stream>>>(n, nchunks, tab, (PT *)sv.price.p, (int *)sv.owner.p, r2c_full,
+                                                          (int *)sv.pred.p, (const int *)sv.list.p, (int *)sv.misc.p,
+                                                          (SxShared *)sv.xbuf.p);
             TD_HIP(hipGetLastError());
             if (getenv("TD_DEBUG")) {
                 long long dbg[8];
