@@ -47,6 +47,13 @@ extern "C" {
 TD_API int td_init(int device);            /* select GPU, create stream + workspace */
 TD_API void td_shutdown(void);
 TD_API const char *td_last_error(void);
+/* Stream rule: every entry point enqueues on ONE stream (the library's own unless td_set_stream
+ * gave it the caller's). Device INPUTS must be complete in that stream's order, device OUTPUTS of
+ * the asynchronous entry points (td_cost_build, td_gen_uniform with a device destination) are
+ * ready in that stream's order: a caller working on another stream either shares its stream
+ * with td_set_stream or fences with its own synchronisation / td_synchronize. Entry points that
+ * return values to the host (td_assign, td_lcm, td_pool2, td_count_sum) return after their
+ * results are complete. */
 TD_API int td_set_stream(void *hip_stream); /* run on the caller's stream (NULL -> library stream) */
 TD_API int td_synchronize(void);
 TD_API int td_version(void);

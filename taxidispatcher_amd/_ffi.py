@@ -133,6 +133,13 @@ def addr(a):
     if isinstance(a, np.ndarray):
         return a.ctypes.data
     if hasattr(a, "data_ptr"):
+        # The library works on its own HIP stream (td_set_stream changes that). A CUDA tensor may
+        # still be being written by kernels queued on torch's current stream, and torch may hand
+        # its memory to the next tensor the moment it is released: fence torch's stream before
+        # the library sees the pointer.
+        if getattr(a, "is_cuda", False):
+            import torch
+            torch.cuda.current_stream(a.device).synchronize()
         return a.data_ptr()
     raise TypeError("cannot take the address of %r" % type(a))
 

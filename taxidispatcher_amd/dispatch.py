@@ -72,6 +72,9 @@ def cost_build(cab_to, dem_from, distances=None, fill=BIG_COST, threshold=-1, ca
         _ffi.check(lib.td_cost_build(_ffi.addr(cab_to), _ffi.addr(cab_id), n_s, _ffi.addr(dem_from),
                                      _ffi.addr(dem_id), n_d, dptr, S, int(fill), int(threshold), int(bool(by_id)),
                                      _ffi.addr(out)))
+        if getattr(out, "is_cuda", False):
+            # device output: written asynchronously on the library's stream; torch works on its own
+            _ffi.check(lib.td_synchronize())
     del keep
     return n, out
 
