@@ -465,9 +465,12 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nrows, int 
 // =====================================================================================
 // state init
 // =====================================================================================
+__device__ __forceinline__ void shape_probe(int n, const int32_t *__restrict__ cost, int *__restrict__ ctl);
+
 template <typename PT>
-__global__ void k_init_state(int n, int npad, int nrows, PT *pk, PT padkey, int *owner, int *r2c,
-                             unsigned long long *bid, int *ctl, const int *rconst)
+__global__ __launch_bounds__(256) void k_init_state(int n, int npad, int nrows, PT *pk, PT padkey, int *owner, int *r2c,
+                                                    unsigned long long *bid, int *ctl, const int *rconst,
+                                                    const int32_t *probe_cost /* non-null: run the shape probe */)
 {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < npad) {
@@ -478,6 +481,7 @@ __global__ void k_init_state(int n, int npad, int nrows, PT *pk, PT padkey, int 
     // -1: free row; -2: constant row, deferred to k_place_const (never bids, never searched)
     if (j < nrows) r2c[j] = (rconst && rconst[j]) ? -2 : -1;
     if (j < CTL_WORDS && j != CTL_FLAG && j != CTL_NCONST && j != CTL_RANGE && j != CTL_RANGE + 1) ctl[j] = 0;
+    if (probe_cost) shape_probe(n, probe_cost, ctl);   // uniform: every workgroup takes part in the ticket
 }
 
 // =====================================================================================
@@ -800,11 +804,11 @@ __global__ __launch_bounds__(1024) void k_freelist(int n, const int *__restrict_
 // the columns nobody owns at the end, k-th constant row <- k-th free column. Exactness: a column
 // that was never owned still has price 0 and prices never go below 0, so the row's dual
 // min_j(c + p_j) is attained there and the LP certificate (k_dual) closes as before.
-__global__ __launch_bounds__(1024) void k_place_const(int n, int *__restrict__ r2c, int *__restrict__ owner,
-                                                      int *__restrict__ lista, int *__restrict__ listb,
-                                                      int *__restrict__ ctl)
+__device__ __forceinline__ void place_const_tail(int n, int *__restrict__ r2c, int *__restrict__ owner,
+                                                 int *__restrict__ lista, int *__restrict__ listb,
+                                                 int *__restrict__ ctl)
 {
-    if (ctl[CTL_FLAG] || ctl[CTL_NCONST] == 0) return;
+    if (ctl[CTL_NCONST] == 0) return;
     const int nr = build_free_list(n, r2c, lista, -2);
     if (nr == 0) return;
     const int nc = build_free_list(n, owner, listb, -1);
@@ -819,6 +823,14 @@ __global__ __launch_bounds__(1024) void k_place_const(int n, int *__restrict__ r
     }
 }
 
+__global__ __launch_bounds__(1024) void k_place_const(int n, int *__restrict__ r2c, int *__restrict__ owner,
+                                                      int *__restrict__ lista, int *__restrict__ listb,
+                                                      int *__restrict__ ctl)
+{
+    if (ctl[CTL_FLAG]) return;
+    place_const_tail(n, r2c, owner, lista, listb, ctl);
+}
+
 // Shape probe (td_assign, speculative attempt only, right after the compress pass): 16 sampled
 // rows estimate how many COLUMNS are constant; the compress pass has counted the constant rows
 // exactly. Many constant columns (dummy requests of a padded rectangular model,
@@ -827,7 +839,7 @@ __global__ __launch_bounds__(1024) void k_place_const(int n, int *__restrict__ r
 // constant ROWS, which are deferred. Sets CTL_FLAG bit 2 -> every later kernel of the attempt
 // exits, the host transposes and redoes. The probe only picks the cheaper of two exact
 // formulations; its estimate needs no guarantee.
-__global__ __launch_bounds__(256) void k_shape(int n, const int32_t *__restrict__ cost, int *__restrict__ ctl)
+__device__ __forceinline__ void shape_probe(int n, const int32_t *__restrict__ cost, int *__restrict__ ctl)
 {
     int *sh = ctl + CTL_SHAPE;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1903,7 +1915,8 @@ template <bool LDSST, bool SPEC>
 __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTab tab, int32_t *__restrict__ pk,
                                                int *__restrict__ owner_g, int *__restrict__ r2c,
                                                int *__restrict__ pred_g, int *__restrict__ list,
-                                               int *__restrict__ ctl, PsRec<int32_t> *__restrict__ recs)
+                                               int *__restrict__ ctl, PsRec<int32_t> *__restrict__ recs,
+                                               int place_const = 0 /* serial form: also place the deferred constant rows */)
 {
     constexpr int E = 16;
     constexpr uint32_t AMAX = 0x7FFFFFFFu;
@@ -1930,6 +1943,7 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
     const int nfree = SPEC ? 1 : ctl[CTL_NFREE];
     if (!SPEC && nfree == 0) {
         if (tid == 0) ctl[CTL_STEPS] = 0;
+        if (place_const) place_const_tail(n, r2c, owner_g, list, pred_g, ctl);
         return;
     }
     if (LDSST)
@@ -2173,6 +2187,11 @@ __global__ __launch_bounds__(1024) void k_sap8(int n, int nchunks, const ShardTa
         ctl[CTL_STEPS] = (int)(steps > INT_MAX ? INT_MAX : steps);
         if (bad) atomicOr(&ctl[CTL_ERR], 2);
     }
+    if (place_const && !bad) {   // owner_g / r2c were written through by thread 0
+        __threadfence();
+        __syncthreads();
+        place_const_tail(n, r2c, owner_g, list, pred_g, ctl);
+    }
 }
 
 // =====================================================================================
@@ -2407,6 +2426,8 @@ struct td_shard {
     const int32_t *d_cost = nullptr;  // nrows x n, device
     Buf stage, cc, price, owner, r2c, r2c_full, bid, pred, list, rowmin, rconst, misc, psrec, tbuf, xbuf;
     bool defer_const = false;  // constant rows sit out the solve and take the left-over columns (td_assign only)
+    const int32_t *probe = nullptr;  // non-null for the one k_init_state launch that carries the shape probe
+    bool placed = false;       // ... and the finisher kernel has already placed them (no k_place_const launch)
     void free_all()
     {
         Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &rconst, &misc, &psrec, &tbuf, &xbuf};
@@ -2527,7 +2548,7 @@ int sv_begin_t(Solver &sv)
     const PT padkey = (PT)(Tr<CT>::BIG << 1) | (PT)1;
     k_init_state<PT><<<(std::max(sv.npad, (int)CTL_WORDS) + 255) / 256, 256, 0, c.stream>>>(
         sv.n, sv.npad, sv.nrows, (PT *)sv.price.p, padkey, (int *)sv.owner.p, (int *)sv.r2c.p,
-        (unsigned long long *)sv.bid.p, (int *)sv.misc.p, sv.defer_const ? (const int *)sv.rconst.p : nullptr);
+        (unsigned long long *)sv.bid.p, (int *)sv.misc.p, sv.defer_const ? (const int *)sv.rconst.p : nullptr, sv.probe);
     TD_HIP(hipMemsetAsync((char *)sv.misc.p + 1024, 0, 16, c.stream));
     TD_HIP(hipGetLastError());
     return TD_OK;
@@ -2728,11 +2749,14 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
                 if (shm > 48 * 1024)
                     (void)hipFuncSetAttribute((const void *)k_sap8<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
                 k_sap8<true, false><<<1, T, shm, c.stream>>>(sv.n, sv.nchunks, tab, (int32_t *)sv.price.p, (int *)sv.owner.p, r2c_full,
-                                                             (int *)sv.pred.p, (int *)sv.list.p, (int *)sv.misc.p, nullptr);
+                                                             (int *)sv.pred.p, (int *)sv.list.p, (int *)sv.misc.p, nullptr,
+                                                             sv.defer_const ? 1 : 0);
             } else {
                 k_sap8<false, false><<<1, T, 0, c.stream>>>(sv.n, sv.nchunks, tab, (int32_t *)sv.price.p, (int *)sv.owner.p, r2c_full,
-                                                            (int *)sv.pred.p, (int *)sv.list.p, (int *)sv.misc.p, nullptr);
+                                                            (int *)sv.pred.p, (int *)sv.list.p, (int *)sv.misc.p, nullptr,
+                                                            sv.defer_const ? 1 : 0);
             }
+            sv.placed = sv.defer_const;   // the constant rows were placed by the finisher itself
             TD_HIP(hipGetLastError());
             return TD_OK;
         }
@@ -2952,14 +2976,12 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
             known_range = c.stats[6];
             continue;
         }
-        if (spec && orient == 0 && g_shape && n >= 64 && n <= g_shape_max_n && !g_solver_eps && !fuse0) {
-            // shape probe: may ask (CTL_FLAG bit 2) for the transposed formulation; like a failed
-            // width speculation this costs one empty pass through the early-exiting kernels
-            ProfScope ps(TD_K_FINAL);
-            k_shape<<<(n + 255) / 256, 256, 0, c.stream>>>(n, sv.d_cost, (int *)sv.misc.p);
-        }
+        // shape probe (inside k_init_state): may ask (CTL_FLAG bit 2) for the transposed formulation;
+        // like a failed width speculation this costs one empty pass through the early-exiting kernels
+        sv.probe = (spec && orient == 0 && g_shape && n >= 64 && n <= g_shape_max_n && !g_solver_eps && !fuse0) ? sv.d_cost : nullptr;
         if (!fuse0) {
             TD_DISPATCH(sv, sv_begin_t, sv);
+            sv.probe = nullptr;
             if (rc) return rc;
         }
         if (g_solver_eps) {
@@ -2992,9 +3014,10 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         tab.p[0] = sv.cc.p;
         tab.rps = n;
         tab.count = 1;
+        sv.placed = false;
         TD_DISPATCH(sv, sv_finish_t, sv, tab, (int *)sv.r2c.p);
         if (rc) return rc;
-        if (sv.defer_const) {
+        if (sv.defer_const && !sv.placed) {
             ProfScope ps(TD_K_FINAL);
             k_place_const<<<1, 1024, 0, c.stream>>>(n, (int *)sv.r2c.p, (int *)sv.owner.p, (int *)sv.list.p, (int *)sv.pred.p,
                                                    (int *)sv.misc.p);
