@@ -179,7 +179,7 @@ TD_API int td_memcpy(void *dst, const void *src, uint64_t bytes);
 TD_API int td_profile_enable(int on);                      /* HIP-event timing per kernel class */
 TD_API int td_profile_get(int kernel, double *total_ms, int64_t *launches);
 TD_API int td_profile_reset(void);
-/* counters of the last td_assign: [0]=bid rounds, [1]=row scans in bid rounds,
+/* counters of the last td_assign: [0]=bid rounds, [1]=rounds of the eps > 0 price warm start,
  * [2]=free rows left to the serial finisher, [3]=its dijkstra steps, [4]=cost storage bytes per cell,
  * [5]=augmentations committed by the parallel finisher, [7]=1 when the transposed formulation was solved
  * (many constant columns, see DESIGN.md "rectangular models") */

@@ -83,7 +83,8 @@ enum {
     // shape probe (k_shape): [+0] constant-looking columns, [+1] rows, [+2] block ticket,
     // [+3] 1 = solve the transpose, [+4..5] 64-bit largest sampled column range
     CTL_SHAPE = CTL_WORDS,
-    CTL_PSTOP = CTL_WORDS + 6,   // a speculative batch committed nothing: later batches of the group exit at once
+    CTL_PSTOP = CTL_WORDS + 6,
+    CTL_TIED = CTL_WORDS + 7,    // rows whose two smallest costs are equal (counted by bidding round 0)   // a speculative batch committed nothing: later batches of the group exit at once
     CTL_ALL = CTL_WORDS + 8
 };
 
@@ -106,6 +107,14 @@ int g_psap8_grid = 64;      // TD_PSAP8_GRID    searches per such batch
 int g_psap_batches = 16;    // TD_PSAP          speculative batches per group of the generic search (u16 / u32 rows)
 int g_psap_min = 12;        // TD_PSAP_MIN      free rows below which the generic batches are skipped
 int g_psap_cap = 4096;      // TD_PSAP_CAP      total speculative batches per solve
+int g_warm = 1;             // TD_WARM          eps > 0 auction phases as a price warm start for wide, tie-free rows
+int g_warm_div = 4;         // TD_WARM_DIV      first eps = row range / this
+int g_warm_theta = 2;       // TD_WARM_THETA    eps divided by this between phases
+int g_warm_bits = 30;       // TD_WARM_BITS     last eps >= row range >> this
+int g_warm_groups = 32;     // TD_WARM_GROUPS   groups of 8 rounds per phase at most
+int g_warm_cut = 64;        // TD_WARM_CUT      a phase ends when <= n / this rows are free (0: none)
+int g_warm_min_range = 256; // TD_WARM_MIN_RANGE rows narrower than this are never warmed
+int g_warm_minfree = 32;    // TD_WARM_MINFREE  free rows after the eps = 0 rounds below which the finisher is cheaper
 int g_sapx = 1;             // TD_SAPX          cooperative multi-workgroup serial finisher (k_sapx)
 int g_sapx_t = 256;         // TD_SAPX_T        threads per workgroup of k_sapx (64: one wavefront on up to 64 CUs, measured slower)
 int g_sapx_min = 8;         // TD_SAPX_MIN      fewest workgroups (256 chunks each) for which it is used
@@ -136,6 +145,14 @@ void read_tunables()
     if (const char *e = getenv("TD_PSAP_CAP")) g_psap_cap = std::max(0, atoi(e));
     if (const char *e = getenv("TD_SAP512")) g_sap512 = atoi(e) != 0;
     if (const char *e = getenv("TD_SAPX")) g_sapx = atoi(e) != 0;
+    if (const char *e = getenv("TD_WARM")) g_warm = atoi(e) != 0;
+    if (const char *e = getenv("TD_WARM_DIV")) g_warm_div = std::max(1, atoi(e));
+    if (const char *e = getenv("TD_WARM_THETA")) g_warm_theta = std::max(2, atoi(e));
+    if (const char *e = getenv("TD_WARM_BITS")) g_warm_bits = std::max(1, std::min(30, atoi(e)));
+    if (const char *e = getenv("TD_WARM_GROUPS")) g_warm_groups = std::max(1, atoi(e));
+    if (const char *e = getenv("TD_WARM_CUT")) g_warm_cut = std::max(0, atoi(e));
+    if (const char *e = getenv("TD_WARM_MIN_RANGE")) g_warm_min_range = std::max(1, atoi(e));
+    if (const char *e = getenv("TD_WARM_MINFREE")) g_warm_minfree = std::max(1, atoi(e));
     if (const char *e = getenv("TD_SAPX_MIN")) g_sapx_min = std::max(1, atoi(e));
     if (const char *e = getenv("TD_SAPX_T")) g_sapx_t = atoi(e) == 64 ? 64 : 256;
     if (const char *e = getenv("TD_PSAP_WORTH")) g_psap_worth = std::max(1, atoi(e));
@@ -496,7 +513,8 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nrows, int
                                                           const int *__restrict__ r2c,
                                                           unsigned long long *__restrict__ bid,
                                                           const int *__restrict__ ctl, int round, int tie_evict,
-                                                          long long kscale = 1, long long eps = 0)
+                                                          long long kscale = 1, long long eps = 0,
+                                                          int *__restrict__ tied = nullptr /* round 0: count rows tied at their minimum */)
 {
     using PT = typename Tr<CT>::PT;
     constexpr int E = Tr<CT>::E;
@@ -595,6 +613,7 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nrows, int
             const int j1 = ch * E + (bp - t1 * E);
             const PT inc = (x == Tr<CT>::KMAX) ? (PT)0 : (PT)((x >> 1) - (bk >> 1));
             const bool owned = (bk & 1) != 0;
+            if (tied && inc == 0) atomicAdd(tied, 1);
             // A tie on an owned column raises no price.  With tie_evict the row still takes the
             // column (complementary slackness stays exact, the previous owner re-bids next round
             // and usually finds a free tied column); otherwise it is left to the finisher.
@@ -2426,6 +2445,7 @@ struct td_shard {
     const int32_t *d_cost = nullptr;  // nrows x n, device
     Buf stage, cc, price, owner, r2c, r2c_full, bid, pred, list, rowmin, rconst, misc, psrec, tbuf, xbuf;
     bool defer_const = false;  // constant rows sit out the solve and take the left-over columns (td_assign only)
+    int nconst = -1;                 // constant rows counted by the last compress pass (-1: not read back)
     const int32_t *probe = nullptr;  // non-null for the one k_init_state launch that carries the shape probe
     bool placed = false;       // ... and the finisher kernel has already placed them (no k_place_const launch)
     void free_all()
@@ -2516,10 +2536,12 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false, bool bid0 = fa
         // do not stall the stream on the "row range fits" flag: carry on as if it fits; the flag
         // comes back with the final read-back and a wrong guess is simply redone one width up
         *fits = true;
+        sv.nconst = -1;   // not known on the host
     } else {
         TD_HIP(hipMemcpyAsync(c.pinned, ctl, 8 * sizeof(int), hipMemcpyDeviceToHost, c.stream));
         TD_HIP(hipStreamSynchronize(c.stream));
         *fits = (((int *)c.pinned)[CTL_FLAG] == 0);
+        sv.nconst = ((int *)c.pinned)[CTL_NCONST];
         if (!*fits) c.stats[6] = (int64_t)(((const unsigned long long *)((int *)c.pinned + CTL_RANGE))[0]);
     }
     if (*fits) {
@@ -2565,18 +2587,19 @@ int sv_bid_t(Solver &sv, int r, unsigned long long *keys)
     const bool can_lds = lds_prices <= 128 * 1024 && n >= 2048 && nrows >= 1024;
     const int tie_evict = (r >= 1) ? g_tie_evict : 0;
     ProfScope ps(TD_K_BID);
+    int *tied = (r == 0) ? (int *)sv.misc.p + CTL_TIED : nullptr;
     if (can_lds && r < g_lds_rounds) {
         if (lds_prices > 48 * 1024)
             (void)hipFuncSetAttribute((const void *)k_bid<CT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prices);
         const int grid = std::min((nrows + 15) / 16, c.n_cu * g_lds_grid);
         k_bid<CT, true><<<grid, 1024, lds_prices, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
-                                                              (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict);
+                                                              (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict, 1, 0, tied);
     } else if (r >= g_row_rounds) {
         k_bid_row<CT><<<nrows, 256, 0, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
                                                    (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict);
     } else {
         k_bid<CT, false><<<(nrows + 3) / 4, 256, 0, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
-                                                                (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict);
+                                                                (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict, 1, 0, tied);
     }
     TD_HIP(hipGetLastError());
     return TD_OK;
@@ -2859,6 +2882,54 @@ int sv_solve_eps_t(Solver &sv, long long eps0_mult, int theta, int64_t *rounds_o
     return TD_OK;
 }
 
+// Price warm start for wide, tie-free rows (|a-b| geometry, uniform 0..10^6): the eps = 0 rounds
+// stall there with a quarter of the rows free (every bid evicts somebody, increments are the tiny
+// gaps between best and second best) and leave thousands of long augmenting paths to the finisher.
+// A few Bertsekas auction phases with eps = range/4, /16, ... (integer eps on the unscaled costs,
+// each phase cut off once 98 % of the rows are placed) bring the prices close to equilibrium in a
+// few dozen streaming rounds. Only the PRICES are kept: any non-negative price vector is dual
+// feasible, so exactness still rests on the eps = 0 rounds + shortest augmenting paths + the LP
+// certificate that follow; the assignment of the eps phases is thrown away.
+template <typename CT>
+int sv_warm_t(Solver &sv, int64_t range, int64_t *rounds_out)
+{
+    Ctx &c = ctx();
+    using PT = typename Tr<CT>::PT;
+    const int n = sv.n;
+    unsigned long long *keys = (unsigned long long *)sv.bid.p;
+    const long long eps_last = std::max<long long>(1, range >> g_warm_bits);
+    int64_t rounds = 0;
+    bool first = true;
+    ProfScope ps(TD_K_BID);
+    for (long long eps = std::max<long long>(1, range / g_warm_div);; eps = std::max<long long>(eps_last, eps / g_warm_theta)) {
+        (void)first;
+        k_eps_reset<PT><<<(std::max(n, (int)CTL_WORDS) + 255) / 256, 256, 0, c.stream>>>(n, sv.nrows, (PT *)sv.price.p, (int *)sv.owner.p,
+                                                                                           (int *)sv.r2c.p, (int *)sv.misc.p);
+        first = false;
+        for (int grp = 0; grp < g_warm_groups; grp++) {
+            for (int r = 0; r < 8; r++) {
+                k_bid<CT, false, true><<<(sv.nrows + 3) / 4, 256, 0, c.stream>>>(n, sv.nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p,
+                                                                               (const PT *)sv.price.p, (const int *)sv.r2c.p, keys,
+                                                                               (const int *)sv.misc.p, 60, 1, 1, eps);
+                k_assign<PT><<<(n + 255) / 256, 256, 0, c.stream>>>(n, sv.nrows, sv.row0, keys, (PT *)sv.price.p, (int *)sv.owner.p,
+                                                                   (int *)sv.r2c.p, (int *)sv.misc.p, 60);
+            }
+            rounds += 8;
+            k_freelist<<<1, 1024, 0, c.stream>>>(n, (const int *)sv.r2c.p, (int *)sv.list.p, (int *)sv.misc.p);
+            TD_HIP(hipMemcpyAsync(c.pinned, (int *)sv.misc.p + CTL_NFREE, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+            TD_HIP(hipStreamSynchronize(c.stream));
+            if (((int *)c.pinned)[0] <= (g_warm_cut > 0 ? n / g_warm_cut : 0)) break;
+        }
+        if (eps <= eps_last) break;
+    }
+    // keep the prices, drop the assignment
+    k_eps_reset<PT><<<(std::max(n, (int)CTL_WORDS) + 255) / 256, 256, 0, c.stream>>>(n, sv.nrows, (PT *)sv.price.p, (int *)sv.owner.p,
+                                                                                   (int *)sv.r2c.p, (int *)sv.misc.p);
+    TD_HIP(hipGetLastError());
+    *rounds_out = rounds;
+    return TD_OK;
+}
+
 #define TD_DISPATCH(sv, CALL, ...)                                  \
     do {                                                            \
         switch ((sv).bpc) {                                         \
@@ -2984,6 +3055,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
             sv.probe = nullptr;
             if (rc) return rc;
         }
+        int64_t warm_rounds = 0;
         if (g_solver_eps) {
             int64_t er = 0, ep = 0;
             TD_DISPATCH(sv, sv_solve_eps_t, sv, g_eps0_mult, g_eps_theta, &er, &ep);
@@ -3002,12 +3074,27 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
             solved = true;
             break;
         }
-        for (int r = 0; r < max_rounds; r++) {
-            if (!(r == 0 && sv.fused_bid0)) {
-                TD_DISPATCH(sv, sv_bid_t, sv, r, (unsigned long long *)sv.bid.p);
+        for (int pass = 0; pass < 2; pass++) {
+            for (int r = 0; r < max_rounds; r++) {
+                if (!(r == 0 && sv.fused_bid0 && pass == 0)) {
+                    TD_DISPATCH(sv, sv_bid_t, sv, r, (unsigned long long *)sv.bid.p);
+                    if (rc) return rc;
+                }
+                TD_DISPATCH(sv, sv_apply_t, sv, r, (unsigned long long *)sv.bid.p);
                 if (rc) return rc;
             }
-            TD_DISPATCH(sv, sv_apply_t, sv, r, (unsigned long long *)sv.bid.p);
+            // Wide, tie-free rows (no constant rows, few rows tied at their minimum) that the eps = 0
+            // rounds leave with many free rows: warm the prices with eps > 0 phases (sv_warm_t) and
+            // run the rounds once more. One small read-back; only non-speculative attempts (u16 / u32
+            // rows), which have synchronised for the width flag already.
+            if (pass == 1 || !g_warm || g_solver_eps || spec || bpc == 1 || sv.nconst != 0 || known_range < g_warm_min_range) break;
+            k_freelist<<<1, 1024, 0, c.stream>>>(n, (const int *)sv.r2c.p, (int *)sv.list.p, (int *)sv.misc.p);
+            TD_HIP(hipMemcpyAsync(c.pinned, sv.misc.p, CTL_ALL * sizeof(int), hipMemcpyDeviceToHost, c.stream));
+            TD_HIP(hipStreamSynchronize(c.stream));
+            const int nfree_now = ((int *)c.pinned)[CTL_NFREE], tied0 = ((int *)c.pinned)[CTL_TIED];
+            if (nfree_now < std::max(g_warm_minfree, n / 64) || (long long)tied0 * 8 > n) break;
+            if (bpc == 2) rc = sv_warm_t<uint16_t>(sv, known_range, &warm_rounds);
+            else rc = sv_warm_t<uint32_t>(sv, known_range, &warm_rounds);
             if (rc) return rc;
         }
         ShardTab tab{};
@@ -3026,6 +3113,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         if (rc) return rc;
         int flag = 0;
         if ((rc = sv_readback(sv, &tot, &dual, max_rounds, spec ? &flag : nullptr))) return rc;
+        c.stats[1] = warm_rounds;
         if (spec && (flag & 4)) {  // many constant columns: solve the transposed problem instead
             want_transpose = true;
             range_hint = c.stats[6] > 254 ? c.stats[6] : -1;

@@ -108,7 +108,7 @@ def expand_x(n, row_to_col):
 def last_stats():
     out = (ctypes.c_int64 * 8)()
     _ffi.check(_ffi.lib().td_last_stats(out, 8))
-    return {"bid_rounds": out[0], "sap_free_rows": out[2], "sap_steps": out[3], "bytes_per_cell": out[4],
+    return {"bid_rounds": out[0], "warm_rounds": out[1], "sap_free_rows": out[2], "sap_steps": out[3], "bytes_per_cell": out[4],
             "parallel_sap_rows": out[5], "transposed": out[7]}
 
 
