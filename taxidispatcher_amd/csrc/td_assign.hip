@@ -84,7 +84,7 @@ enum {
     // [+3] 1 = solve the transpose, [+4..5] 64-bit largest sampled column range
     CTL_SHAPE = CTL_WORDS,
     CTL_PSTOP = CTL_WORDS + 6,
-    CTL_TIED = CTL_WORDS + 7,    // rows whose two smallest costs are equal (counted by bidding round 0)   // a speculative batch committed nothing: later batches of the group exit at once
+    CTL_TIED = CTL_WORDS + 7,    // rows whose two smallest costs are equal (bidding round 0, every 16th row sampled)   // a speculative batch committed nothing: later batches of the group exit at once
     CTL_ALL = CTL_WORDS + 8
 };
 
@@ -613,7 +613,8 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nrows, int
             const int j1 = ch * E + (bp - t1 * E);
             const PT inc = (x == Tr<CT>::KMAX) ? (PT)0 : (PT)((x >> 1) - (bk >> 1));
             const bool owned = (bk & 1) != 0;
-            if (tied && inc == 0) atomicAdd(tied, 1);
+            // sampled (every 16th row): 16 384 same-address atomics would cost more than the round
+            if (tied && inc == 0 && (row & 15) == 0) atomicAdd(tied, 1);
             // A tie on an owned column raises no price.  With tie_evict the row still takes the
             // column (complementary slackness stays exact, the previous owner re-bids next round
             // and usually finds a free tied column); otherwise it is left to the finisher.
@@ -3092,7 +3093,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
             TD_HIP(hipMemcpyAsync(c.pinned, sv.misc.p, CTL_ALL * sizeof(int), hipMemcpyDeviceToHost, c.stream));
             TD_HIP(hipStreamSynchronize(c.stream));
             const int nfree_now = ((int *)c.pinned)[CTL_NFREE], tied0 = ((int *)c.pinned)[CTL_TIED];
-            if (nfree_now < std::max(g_warm_minfree, n / 64) || (long long)tied0 * 8 > n) break;
+            if (nfree_now < std::max(g_warm_minfree, n / 64) || (long long)tied0 * 16 * 8 > n) break;   // tied0 counts every 16th row
             if (bpc == 2) rc = sv_warm_t<uint16_t>(sv, known_range, &warm_rounds);
             else rc = sv_warm_t<uint32_t>(sv, known_range, &warm_rounds);
             if (rc) return rc;
