@@ -113,6 +113,7 @@ int g_warm_theta = 2;       // TD_WARM_THETA    eps divided by this between phas
 int g_warm_bits = 30;       // TD_WARM_BITS     last eps >= row range >> this
 int g_warm_groups = 32;     // TD_WARM_GROUPS   groups of 8 rounds per phase at most
 int g_warm_cut = 64;        // TD_WARM_CUT      a phase ends when <= n / this rows are free (0: none)
+int g_warm_keep = 0;        // TD_WARM_KEEP     1: keep the pairs that are tight at the warmed prices (k_keep_tight) instead of dropping the assignment; measured a wash
 int g_warm_min_range = 256; // TD_WARM_MIN_RANGE rows narrower than this are never warmed
 int g_warm_minfree = 32;    // TD_WARM_MINFREE  free rows after the eps = 0 rounds below which the finisher is cheaper
 int g_sapx = 1;             // TD_SAPX          cooperative multi-workgroup serial finisher (k_sapx)
@@ -152,6 +153,7 @@ void read_tunables()
     if (const char *e = getenv("TD_WARM_GROUPS")) g_warm_groups = std::max(1, atoi(e));
     if (const char *e = getenv("TD_WARM_CUT")) g_warm_cut = std::max(0, atoi(e));
     if (const char *e = getenv("TD_WARM_MIN_RANGE")) g_warm_min_range = std::max(1, atoi(e));
+    if (const char *e = getenv("TD_WARM_KEEP")) g_warm_keep = atoi(e) != 0;
     if (const char *e = getenv("TD_WARM_MINFREE")) g_warm_minfree = std::max(1, atoi(e));
     if (const char *e = getenv("TD_SAPX_MIN")) g_sapx_min = std::max(1, atoi(e));
     if (const char *e = getenv("TD_SAPX_T")) g_sapx_t = atoi(e) == 64 ? 64 : 256;
@@ -2391,6 +2393,54 @@ __global__ void k_fill_i32(int *p, int count, int v)
     if (i < count) p[i] = v;
 }
 
+// After the eps > 0 warm start: keep exactly the assigned pairs that are TIGHT at the warmed prices
+// (c'_ij + p_j == min_k (c'_ik + p_k)), free the others. Any price vector is dual feasible, and
+// tight pairs satisfy exact complementary slackness, so the eps = 0 rounds and the shortest
+// augmenting paths continue from a state that already holds most of the matching and whose
+// remaining paths are short. One wave per row; a column has at most one owner, so freeing it
+// races with nobody (other waves only read the price bits of pk[j]).
+template <typename CT>
+__global__ __launch_bounds__(256) void k_keep_tight(int n, int nrows, int row0, int nchunks, const CT *__restrict__ cc,
+                                                    typename Tr<CT>::PT *pk, int *__restrict__ owner,
+                                                    int *__restrict__ r2c, int *__restrict__ ctl)
+{
+    using PT = typename Tr<CT>::PT;
+    constexpr int E = Tr<CT>::E;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const size_t pitch = (size_t)nchunks * E;
+    if (blockIdx.x == 0)
+        for (int j = CTL_PROG + threadIdx.x; j < CTL_WORDS; j += blockDim.x) ctl[j] = 0;
+    for (int row = blockIdx.x * nw + w; row < nrows; row += gridDim.x * nw) {
+        const int j0 = r2c[row];
+        if (j0 < 0) continue;   // free (or deferred) already
+        const CT *rp = cc + (size_t)row * pitch;
+        PT m = Tr<CT>::KMAX;
+        for (int ch = lane; ch < nchunks; ch += 64) {
+            const uint4 cv = *reinterpret_cast<const uint4 *>(rp + (size_t)ch * E);
+            uint32_t c[E];
+            unpack<CT>(cv, c);
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const PT v = (PT)c[e] + (pk[(size_t)ch * E + e] >> 1);
+                m = v < m ? v : m;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            PT om = shfl_xor_t(m, o);
+            m = om < m ? om : m;
+        }
+        if (lane == 0) {
+            const PT mine = (PT)rp[j0] + (pk[j0] >> 1);
+            if (mine != m) {
+                r2c[row] = -1;
+                owner[j0] = -1;
+                pk[j0] = (PT)((pk[j0] >> 1) << 1);   // no owner any more
+            }
+        }
+    }
+}
+
 // dual bound D = sum_i (rowmin_i + min_j (c'_ij + p_j)) - sum_j p_j ; one wave per (local) row
 template <typename CT>
 __global__ __launch_bounds__(256) void k_dual(int n, int nrows, int row0, int nchunks, const CT *__restrict__ cc,
@@ -2923,9 +2973,13 @@ int sv_warm_t(Solver &sv, int64_t range, int64_t *rounds_out)
         }
         if (eps <= eps_last) break;
     }
-    // keep the prices, drop the assignment
-    k_eps_reset<PT><<<(std::max(n, (int)CTL_WORDS) + 255) / 256, 256, 0, c.stream>>>(n, sv.nrows, (PT *)sv.price.p, (int *)sv.owner.p,
-                                                                                   (int *)sv.r2c.p, (int *)sv.misc.p);
+    // keep the prices and the pairs that are exactly tight at them, free the rest
+    if (g_warm_keep)
+        k_keep_tight<CT><<<std::max(1, std::min((sv.nrows + 3) / 4, c.n_cu * 8)), 256, 0, c.stream>>>(
+            n, sv.nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (PT *)sv.price.p, (int *)sv.owner.p, (int *)sv.r2c.p, (int *)sv.misc.p);
+    else
+        k_eps_reset<PT><<<(std::max(n, (int)CTL_WORDS) + 255) / 256, 256, 0, c.stream>>>(n, sv.nrows, (PT *)sv.price.p, (int *)sv.owner.p,
+                                                                                       (int *)sv.r2c.p, (int *)sv.misc.p);
     TD_HIP(hipGetLastError());
     *rounds_out = rounds;
     return TD_OK;
