@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtaxidispatcher_amd.so")
+LIB_PATH = os.environ.get("TD_LIB") or os.path.join(_HERE, "libtaxidispatcher_amd.so")
 
 c_i32p = ctypes.c_void_p  # raw addresses: host numpy buffers or device pointers
 _lib = None

@@ -41,7 +41,7 @@ struct Ctx {
     int n_pend = 0;
     hipEvent_t ev_pool[8192];
     int n_ev = 0, ev_next = 0;
-    int64_t stats[8] = {0};
+    int64_t stats[16] = {0};
 };
 
 Ctx &ctx();

@@ -387,7 +387,7 @@ int td_profile_get(int k, double *ms, int64_t *launches)
 int td_last_stats(int64_t *out, int n)
 {
     TD_REQUIRE_INIT();
-    for (int i = 0; i < n && i < 8; i++) out[i] = ctx().stats[i];
+    for (int i = 0; i < n && i < 16; i++) out[i] = ctx().stats[i];
     return TD_OK;
 }
 
