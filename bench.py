@@ -14,9 +14,14 @@ workload : g1  perf.jl:5 instance family, cost ~ U{10..40}, N = 16384 (BASELINE 
            tick BASELINE configs[4]: one Simulator.java tick (n = 1300 cabs x 900 requests):
                td_cost_build -> td_lcm down to 600 -> shrink -> td_cost_build -> td_assign;
                value = cabs dispatched per second (n / step time), --n is ignored.
---gpus N : one process per GPU (torch.distributed, RCCL).  Instances are independent objects:
-           every rank solves its own instance (different seed) with no data-path collective —
-           weak scaling; value = all instances' assignments / max-over-ranks time.
+--gpus N : one process per GPU (torch.distributed, RCCL).  Started without WORLD_SIZE, bench.py
+           launches the N ranks itself (torch.distributed.run as a child process, before anything
+           touches the GPU).  For N > 1 the headline is BASELINE configs[3]: ONE 65 536 x 65 536
+           instance, rows sharded over the N GPUs, every rank builds its row block in place, one
+           RCCL MAX all-reduce of the packed bid keys per bidding round ("scaling": "strong"; the
+           same instance solved by td_assign on one GPU is timed in the same run).  The replicas
+           figure (an independent N = 16 384 instance per GPU, no collective, weak scaling) is a
+           side field; --multi-mode replicas makes it the headline instead.
 
 Prints ONE JSON line on rank 0.
 """
@@ -49,6 +54,9 @@ def parse():
                     help="with --gpus > 1: also solve ONE instance of this size row-sharded over all ranks "
                          "(BASELINE configs[3]); 0 disables")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--multi-mode", default="sharded", choices=["sharded", "replicas"],
+                    help="headline of a multi-GPU run: the row-sharded single instance (configs[3]) or replicas")
+    ap.add_argument("--no-extras", action="store_true", help="skip the g2 / g3 / tick side measurements (1 GPU)")
     return ap.parse_args()
 
 
@@ -146,36 +154,70 @@ def kernel_profile(wl, ffi, reps):
     return out
 
 
-def sharded_extra(n, world, rank, torch, dist, ffi, reps=3):
-    """BASELINE configs[3]: ONE n x n perf.jl instance row-sharded over all ranks, one RCCL MAX
-    all-reduce of the packed bid keys per bidding round (taxidispatcher_amd/sharded.py).  Reported
-    next to the headline value, never inside it."""
+def sharded_leg(n, world, rank, torch, dist, ffi, steps, warmup):
+    """BASELINE configs[3]: ONE n x n perf.jl instance row-sharded over all ranks.  A step = every
+    rank writes its row block in place (td_gen_uniform with its row window: the synthetic stand-in
+    for the shard-local cost build, td_cost_build_rows) + the sharded solve: one RCCL MAX all-reduce
+    of the packed bid keys per bidding round (taxidispatcher_amd/sharded.py), finisher on rank 0
+    over hipIpc-mapped shards.  W untimed steps, then K steps between barrier + synchronize."""
     from taxidispatcher_amd import sharded
     row0, nrows, _ = sharded.shard_bounds(n, world, rank)
     rows = torch.empty((max(nrows, 1), n), dtype=torch.int32, device="cuda")
-    times, total = [], None
     sh = sharded.HipShard(n, row0, nrows, rows)   # workspace allocated once, reused by every solve
+    total = None
+
+    def step():
+        if nrows:
+            ffi.check(ffi.lib().td_gen_uniform(n, 7, 10, 40, row0, nrows, rows.data_ptr()))
+        return sharded.solve_sharded(sh, dist)[1]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     try:
-        for it in range(reps + 1):
-            torch.cuda.synchronize()
-            dist.barrier()
-            t0 = time.perf_counter()
-            if nrows:
-                ffi.check(ffi.lib().td_gen_uniform(n, 7, 10, 40, row0, nrows, rows.data_ptr()))
-            _, total = sharded.solve_sharded(sh, dist)
-            torch.cuda.synchronize()
-            dist.barrier()
-            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-            if it > 0:
-                times.append(float(dt.item()))
+        for _ in range(warmup):
+            total = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            total = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
     finally:
         sh.close()
-    best = min(times)
-    return {"workload": "g1 N=%d, ONE instance row-sharded over %d GPUs, RCCL MAX all-reduce of %d KiB keys per "
-                        "bidding round, finisher on rank 0 over hipIpc-mapped shards" % (n, world, n * 8 // 1024),
-            "n": n, "ms": 1e3 * best, "ms_all": [1e3 * t for t in times], "assignments_per_s": n / best,
-            "total_cost": int(total), "optimal": bool(total == 10 * n), "scaling": "strong"}
+    del rows
+    torch.cuda.empty_cache()
+    return {"workload": "g1 N=%d, ONE instance row-sharded over %d GPUs (%d rows each), shard-local cost write + "
+                        "RCCL MAX all-reduce of %d KiB keys per bidding round, finisher on rank 0 over hipIpc-mapped "
+                        "shards" % (n, world, nrows, n * 8 // 1024),
+            "n": n, "ms_per_step": 1e3 * dt / steps, "assignments_per_s": n * steps / dt,
+            "total_cost": int(total), "optimal": bool(total == 10 * n), "scaling": "strong", "seconds": dt}
+
+
+def single_gpu_reference(n, torch, ffi, reps=3):
+    """the same n x n instance through td_assign on ONE GPU (rank 0), for the strong-scaling factor"""
+    lib = ffi.lib()
+    cost = torch.empty((n, n), dtype=torch.int32, device="cuda")
+    r2c = torch.empty(n, dtype=torch.int32, device="cuda")
+    tot = ctypes.c_int64(0)
+    ts = []
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ffi.check(lib.td_gen_uniform(n, 7, 10, 40, 0, n, cost.data_ptr()))
+        ffi.check(lib.td_assign(n, cost.data_ptr(), r2c.data_ptr(), ctypes.byref(tot), None))
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    del cost
+    torch.cuda.empty_cache()
+    return {"ms_per_step": 1e3 * min(ts[1:]), "total_cost": int(tot.value)}
 
 
 def cpu_baseline_tick(seconds):
@@ -199,7 +241,7 @@ def cpu_baseline_tick(seconds):
         if time.perf_counter() + spent / reps > t_budget or reps >= 64:
             break
     return {"value": 1300 * reps / spent, "unit": "assignments/s", "cores": 1, "kind": "port",
-            "sample": "%d x (tick: cost build 1300x900 + Java-variant LCM (k full n^2 scans) + cost build + exact "
+            "sample": "stand-in, not GLPK: %d x (tick: cost build 1300x900 + Java-variant LCM (k full n^2 scans) + cost build + exact "
                       "solve n=600, oracle/td_oracle.c, one thread), %.1f s" % (reps, spent),
             "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "last_total": int(tot)}
 
@@ -233,23 +275,26 @@ def cpu_baseline(kind, n_gpu, seconds):
         if time.perf_counter() + spent / reps > t_budget or reps >= 64:
             break
     return {"value": n * reps / spent, "unit": "assignments/s", "cores": 1, "kind": "port",
-            "sample": "%d x (%s instance N=%d: build + exact shortest-augmenting-path solve, oracle/td_oracle.c, "
-                      "gcc -O3, one thread), %.1f s" % (reps, kind, n, spent),
+            "sample": "stand-in, not GLPK: %d x (%s instance N=%d: build + exact shortest-augmenting-path solve, "
+                      "oracle/td_oracle.c, gcc -O3, one thread), %.1f s" % (reps, kind, n, spent),
             "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "last_total": int(tot)}
 
 
+TRAFFIC_PROFILE = os.path.join("profiles", "r1", "rocprof_summary_r1g.json")   # the committed PMC summary the traffic figure is read from
+
+
 def pmc_traffic(kernel_class):
-    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
-    (profiles/*/rocprof_summary*.json, made by tools/profile_round.sh: separate FETCH_SIZE and
-    WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md). None if no summary exists."""
-    import glob
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary named in
+    TRAFFIC_PROFILE (made by tools/profile_round.sh: separate FETCH_SIZE and WRITE_SIZE passes,
+    FETCH_SIZE doubled per MI355X_MICROARCH.md).  Not measured in this run: the line carries the
+    file name as `traffic_source`.  None if the summary is missing."""
     prefix = {"compress": "k_compress", "gen": "k_gen_uniform", "cost_build": "k_cost_build", "bid": "k_bid",
               "sap": "k_sap", "assign": "k_assign", "final": "k_final", "lcm": "k_lcm"}.get(kernel_class)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "rocprof_summary*.json")), key=os.path.getmtime)
-    if not files or not prefix:
+    path = os.path.join(ROOT, TRAFFIC_PROFILE)
+    if not os.path.exists(path) or not prefix:
         return None
     try:
-        t = json.load(open(files[-1])).get("traffic_per_dispatch", {})
+        t = json.load(open(path)).get("traffic_per_dispatch", {})
         best = None
         for k, v in t.items():
             if prefix in k:
@@ -269,8 +314,27 @@ def cpu_model():
     return "unknown"
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of this process
+    (which has not touched the GPU and never will) and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -289,8 +353,7 @@ def main():
     import taxidispatcher_amd as td
     from taxidispatcher_amd import _ffi as ffi
     td.init(local)
-    # run on torch's current stream so that torch events / synchronize bracket our kernels
-    ffi.check(ffi.lib().td_set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    # the library runs on its own stream; the timed region is bracketed by device-wide synchronisation
 
     if args.workload == "tick":
         wl = TickWorkload(1 + rank, td)
@@ -319,16 +382,21 @@ def main():
     stats = td.last_stats()
 
     prof = kernel_profile(wl, ffi, reps=3) if rank == 0 else {}
-    shard_res = None
+    shard_res, single_ref = None, None
     if world > 1 or args.force_sharded:
         dist.barrier()
         if args.sharded_n > 0:
             del wl.cost
             torch.cuda.empty_cache()
             try:
-                shard_res = sharded_extra(args.sharded_n, world, rank, torch, dist, ffi)
-            except Exception as e:  # keep the headline line even if the extra leg fails
+                shard_res = sharded_leg(args.sharded_n, world, rank, torch, dist, ffi, max(1, args.steps), args.warmup)
+                if rank == 0:
+                    single_ref = single_gpu_reference(args.sharded_n, torch, ffi)
+                    shard_res["single_gpu_ms_per_step"] = single_ref["ms_per_step"]
+                    shard_res["speedup_vs_single_gpu"] = single_ref["ms_per_step"] / shard_res["ms_per_step"]
+            except Exception as e:  # keep the replicas line even if this leg fails
                 shard_res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        dist.barrier()
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -348,7 +416,7 @@ def main():
         b = alg_bytes[dom]
         achieved = b / (p["avg_us"] * 1e-6) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom), "traffic_source": TRAFFIC_PROFILE,
                 "algorithmic_bytes_per_launch": b, "avg_launch_us": p["avg_us"], "launches_per_step": p["launches"],
                 "largest_class_by_time": max(prof, key=lambda k: prof[k]["total_ms"])}
     line = {
@@ -364,6 +432,39 @@ def main():
     }
     if shard_res is not None:
         line["sharded_single_instance"] = shard_res
+        if world > 1 and args.multi_mode == "sharded" and "error" not in shard_res:
+            # multi-GPU headline = BASELINE configs[3]; the replicas figure measured above moves to a side field
+            line["replicas"] = {"value": value, "ms_per_step": ms_per_step, "scaling": "weak",
+                                "workload": line["config"]["workload"] + " (one independent instance per GPU, no collective)"}
+            sn = shard_res["n"]
+            line.update({"value": shard_res["assignments_per_s"], "ms_per_step": shard_res["ms_per_step"],
+                         "scaling": "strong",
+                         "config": {"workload": shard_res["workload"], "n": sn, "instances_per_step": 1,
+                                    "parallelism": "rows sharded over %d GPUs, RCCL MAX all-reduce per bidding round" % world},
+                         "pairs_per_s": float(sn) * sn * 1e3 / shard_res["ms_per_step"],
+                         "whole_step_algorithmic_GBps": 8.0 * sn * sn / (shard_res["ms_per_step"] * 1e-3) / 1e9,
+                         "total_cost": shard_res["total_cost"]})
+    if world == 1 and not args.no_extras and args.workload == "g1":
+        # the other workloads of SURVEY 8d / BASELINE configs, measured in the same run (side fields)
+        extras = {}
+        del wl.cost
+        torch.cuda.empty_cache()
+        for name, kind, en, reps in (("tick_1300x900", "tick", 0, 10), ("g3_n16384", "g3", 16384, 5), ("g2_n16384", "g2", 16384, 2)):
+            try:
+                w2 = TickWorkload(1, td) if kind == "tick" else Workload(kind, en, 1, torch, td, ffi)
+                w2.step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    w2.step()
+                torch.cuda.synchronize()
+                e_ms = 1e3 * (time.perf_counter() - t1) / reps
+                extras[name] = {"ms_per_step": e_ms, "assignments_per_s": w2.n / (e_ms * 1e-3), "solver_stats": td.last_stats()}
+                del w2
+                torch.cuda.empty_cache()
+            except Exception as e:
+                extras[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        line["other_workloads"] = extras
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.workload, n, args.cpu_seconds)
     if dist.is_initialized():

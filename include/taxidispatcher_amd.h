@@ -76,6 +76,15 @@ TD_API int td_cost_build(const int32_t *cab_to, const int32_t *cab_id, int n_s,
                   const int32_t *dist, int S, int32_t fill, int32_t threshold, int by_id,
                   int32_t *cost /* n*n */);
 
+/* Row window of the same matrix: writes rows [row0, row0 + nrows) of the n x n model into
+ * cost_rows (nrows * n int32).  This is how a row shard builds its block in place from the
+ * replicated position arrays: every rank passes the full cab_to / dem_from (<= 256 KiB
+ * each) and its own window; no communication.  With by_id the window applies to the cab ids. */
+TD_API int td_cost_build_rows(const int32_t *cab_to, const int32_t *cab_id, int n_s,
+                       const int32_t *dem_from, const int32_t *dem_id, int n_d,
+                       const int32_t *dist, int S, int32_t fill, int32_t threshold, int by_id,
+                       int row0, int nrows, int32_t *cost_rows /* nrows*n */);
+
 /* ---- a-4 optimal assignment --------------------------------------------------------
  * Replaces solve(n, cost) at solver.py:11-27 (and the ilp call at procedure.py:27,
  * greedy_opt.py:117, simulate.py:52, heuristic.py:37): min sum c[i][j] x[i][j], every row
@@ -151,7 +160,11 @@ typedef struct td_shard td_shard;
 TD_API int td_shard_create(int n, int row0, int nrows, const int32_t *cost_rows, td_shard **out);
 TD_API int td_shard_destroy(td_shard *s);
 TD_API int td_shard_compress(td_shard *s, int bytes_per_cell, int *fits);
-TD_API int td_shard_begin(td_shard *s);
+/* largest row cost range (max - min) this shard has seen so far; the caller reduces it with MAX over
+ * the ranks and hands the result to td_shard_begin, which applies td_assign's TD_ERANGE guard
+ * ((range + 1) * (n + 1) must stay below 4e12: the packed bid key holds price << 20 | row) */
+TD_API int td_shard_range(td_shard *s, int64_t *range);
+TD_API int td_shard_begin(td_shard *s, int64_t global_range /* < 0: use this shard's own */);
 TD_API int td_shard_keys_len(td_shard *s);
 TD_API int td_shard_bid(td_shard *s, int round, uint64_t *keys);
 TD_API int td_shard_apply(td_shard *s, int round, uint64_t *keys);

@@ -27,6 +27,8 @@ SIGNATURES = {
     "td_version": (ctypes.c_int, []),
     "td_cost_build": (ctypes.c_int, [c_i32p, c_i32p, ctypes.c_int, c_i32p, c_i32p, ctypes.c_int, c_i32p, ctypes.c_int,
                                      ctypes.c_int32, ctypes.c_int32, ctypes.c_int, c_i32p]),
+    "td_cost_build_rows": (ctypes.c_int, [c_i32p, c_i32p, ctypes.c_int, c_i32p, c_i32p, ctypes.c_int, c_i32p, ctypes.c_int,
+                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p]),
     "td_assign": (ctypes.c_int, [ctypes.c_int, c_i32p, c_i32p, ctypes.POINTER(ctypes.c_int64),
                                  ctypes.POINTER(ctypes.c_int64)]),
     "td_expand_x": (ctypes.c_int, [ctypes.c_int, c_i32p, ctypes.c_void_p]),
@@ -43,7 +45,8 @@ SIGNATURES = {
     "td_shard_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_void_p)]),
     "td_shard_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "td_shard_compress": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
-    "td_shard_begin": (ctypes.c_int, [ctypes.c_void_p]),
+    "td_shard_range": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
+    "td_shard_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
     "td_shard_keys_len": (ctypes.c_int, [ctypes.c_void_p]),
     "td_shard_bid": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "td_shard_apply": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),

@@ -100,7 +100,6 @@ int g_row_rounds = 2;       // TD_ROW_ROUNDS    from this round on: one workgrou
 int g_cgrid = 6;            // TD_CGRID         workgroups per CU of the compress pass
 int g_creg = 1;             // TD_CREG          register-resident compress kernel
 int g_speculate = 1;        // TD_SPECULATE     try u8 storage without waiting for the range flag
-int g_fuse_bid0 = 0;        // TD_FUSE_BID0     round 0 inside the compress pass: measured slower (0.431 vs 0.268+0.085 ms)
 int g_sap8 = 1;             // TD_SAP8          lean u8 finisher
 int g_psap8_batches = 1;    // TD_PSAP8         speculative batches of the lean u8 search
 int g_psap8_grid = 64;      // TD_PSAP8_GRID    searches per such batch
@@ -113,16 +112,12 @@ int g_warm_theta = 2;       // TD_WARM_THETA    eps divided by this between phas
 int g_warm_bits = 30;       // TD_WARM_BITS     last eps >= row range >> this
 int g_warm_groups = 32;     // TD_WARM_GROUPS   groups of 8 rounds per phase at most
 int g_warm_cut = 64;        // TD_WARM_CUT      a phase ends when <= n / this rows are free (0: none)
-int g_warm_keep = 0;        // TD_WARM_KEEP     1: keep the pairs that are tight at the warmed prices (k_keep_tight) instead of dropping the assignment; measured a wash
 int g_warm_min_range = 256; // TD_WARM_MIN_RANGE rows narrower than this are never warmed
 int g_warm_minfree = 32;    // TD_WARM_MINFREE  free rows after the eps = 0 rounds below which the finisher is cheaper
 int g_sapx = 1;             // TD_SAPX          cooperative multi-workgroup serial finisher (k_sapx)
-int g_sapx_t = 256;         // TD_SAPX_T        threads per workgroup of k_sapx (64: one wavefront on up to 64 CUs, measured slower)
 int g_sapx_min = 8;         // TD_SAPX_MIN      fewest workgroups (256 chunks each) for which it is used
 int g_sap512 = 1;           // TD_SAP512        512-thread generic finisher (double register budget) for n <= 8192
 int g_psap_worth = 4;       // TD_PSAP_WORTH    rows a batch must commit on average for another group to be launched
-int g_psap_u8 = 0;          // TD_PSAP_U8       generic batches for u8 rows too (slower than the lean path)
-int g_onewave = 0;          // TD_ONEWAVE       single-wavefront generic finisher for small models (no gain)
 int g_defer_const = 1;      // TD_DEFER_CONST   constant rows sit out the solve (k_place_const)
 int g_shape = 1;            // TD_SHAPE         probe for constant columns and solve the transpose when they dominate
 int g_shape_max_n = 1 << 20; // TD_SHAPE_MAX_N   largest n the probe runs for
@@ -160,14 +155,10 @@ void read_tunables()
     if (const char *e = getenv("TD_WARM_GROUPS")) g_warm_groups = std::max(1, atoi(e));
     if (const char *e = getenv("TD_WARM_CUT")) g_warm_cut = std::max(0, atoi(e));
     if (const char *e = getenv("TD_WARM_MIN_RANGE")) g_warm_min_range = std::max(1, atoi(e));
-    if (const char *e = getenv("TD_WARM_KEEP")) g_warm_keep = atoi(e) != 0;
     if (const char *e = getenv("TD_WARM_MINFREE")) g_warm_minfree = std::max(1, atoi(e));
     if (const char *e = getenv("TD_SAPX_MIN")) g_sapx_min = std::max(1, atoi(e));
-    if (const char *e = getenv("TD_SAPX_T")) g_sapx_t = atoi(e) == 64 ? 64 : 256;
     if (const char *e = getenv("TD_PSAP_WORTH")) g_psap_worth = std::max(1, atoi(e));
-    if (const char *e = getenv("TD_PSAP_U8")) g_psap_u8 = atoi(e) != 0;
     if (const char *e = getenv("TD_SPECULATE")) g_speculate = atoi(e) != 0;
-    if (const char *e = getenv("TD_FUSE_BID0")) g_fuse_bid0 = atoi(e) != 0;
     if (const char *e = getenv("TD_LDS_GRID")) g_lds_grid = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("TD_CORE")) g_core = atoi(e) != 0;
     if (const char *e = getenv("TD_CORE_K")) g_core_k = std::max(2, std::min(256, atoi(e)));
@@ -179,7 +170,6 @@ void read_tunables()
     if (const char *e = getenv("TD_SOLVER")) g_solver_eps = (strcmp(e, "eps") == 0);
     if (const char *e = getenv("TD_EPS0_MULT")) g_eps0_mult = std::max(0ll, atoll(e));
     if (const char *e = getenv("TD_EPS_THETA")) g_eps_theta = std::max(2, atoi(e));
-    if (const char *e = getenv("TD_ONEWAVE")) g_onewave = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("TD_PSAP8")) g_psap8_batches = std::max(0, std::min(32, atoi(e)));
     if (const char *e = getenv("TD_DEFER_CONST")) g_defer_const = atoi(e) != 0;
     if (const char *e = getenv("TD_SHAPE")) g_shape = atoi(e) != 0;
@@ -334,21 +324,14 @@ __global__ __launch_bounds__(256) void k_compress(int n, int nrows, int nchunks,
 // Register-resident variant: the row is read ONCE from HBM (all VPT 16-byte loads of a thread
 // are issued back to back, so a 256-thread workgroup keeps 64 KiB in flight), reduced, and
 // written back narrow.  Needs n % 4 == 0, a 16-byte aligned matrix and n/4 <= THREADS*VPT.
-// BID0: also performs bidding round 0 for the row while it is in registers (prices are all zero and
-// every column is free in round 0, so the bid needs nothing but the row): saves the first 1-byte
-// pass over the narrow copy and one launch.  Same rotation hash and tie-break as k_bid, so the
-// fused and the separate round 0 publish identical keys.
-template <typename CT, int VPT, int THREADS, bool BID0 = false>
+template <typename CT, int VPT, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nrows, int nchunks, const int32_t *__restrict__ cost,
                                                           CT *__restrict__ cc, int32_t *__restrict__ rowmin,
-                                                          int *__restrict__ ctl, int *__restrict__ rconst,
-                                                          unsigned long long *__restrict__ bid = nullptr, int row0 = 0)
+                                                          int *__restrict__ ctl, int *__restrict__ rconst)
 {
     constexpr int E = Tr<CT>::E;
     constexpr int NW = THREADS / 64;
     __shared__ int s_mn[2][NW], s_mx[2][NW];
-    __shared__ long long s_bk[2][NW], s_bx[2][NW];
-    __shared__ int s_bpz[2][NW];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const size_t pitch = (size_t)nchunks * E;
     const int nq = n >> 2;
@@ -421,77 +404,6 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nrows, int 
         }
         // sentinel tail up to the 16-byte chunk boundary
         for (int j = n + tid; j < (int)pitch; j += THREADS) dst[j] = (CT)Tr<CT>::SENT;
-        if constexpr (BID0) {
-            using PT = typename Tr<CT>::PT;
-            const int grow = row0 + row;
-            const uint32_t hsh = ((uint32_t)grow + 1u) * 0x9E3779B1u;  // round 0
-            const int rot = (int)(((uint64_t)(hsh ^ (hsh >> 15)) * (uint64_t)nchunks) >> 32);
-            PT k1 = Tr<CT>::KMAX, k2 = Tr<CT>::KMAX;
-            int pos1 = INT_MAX;
-#pragma unroll
-            for (int k = 0; k < VPT; k++) {
-                const int q = k * THREADS + tid;
-                if (q < nq) {
-                    const int col0 = q << 2;
-                    int t = (col0 / E) - rot;
-                    t += (t < 0) ? nchunks : 0;
-                    const int pb = t * E + (col0 % E);
-                    const int vv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const PT key = (PT)2 * (PT)(uint32_t)(vv[e] - mn);
-                        const int pos = pb + e;
-                        const bool lt = (key < k1) || (key == k1 && pos < pos1);
-                        const PT loser = lt ? k1 : key;
-                        k2 = k2 < loser ? k2 : loser;
-                        k1 = lt ? key : k1;
-                        pos1 = lt ? pos : pos1;
-                    }
-                }
-            }
-            PT bk = k1;
-            int bp = pos1;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const PT ok = shfl_xor_t(bk, o);
-                const int op = __shfl_xor(bp, o);
-                if (ok < bk || (ok == bk && op < bp)) {
-                    bk = ok;
-                    bp = op;
-                }
-            }
-            const bool winner = (k1 == bk) && (bp == pos1) && (pos1 != INT_MAX);
-            PT x = winner ? k2 : k1;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const PT ox = shfl_xor_t(x, o);
-                x = ox < x ? ox : x;
-            }
-            if (lane == 0) {
-                s_bk[par][w] = (long long)bk;
-                s_bpz[par][w] = bp;
-                s_bx[par][w] = (long long)x;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int wb = 0;
-                for (int k = 1; k < NW; k++)
-                    if (s_bk[par][k] < s_bk[par][wb] || (s_bk[par][k] == s_bk[par][wb] && s_bpz[par][k] < s_bpz[par][wb])) wb = k;
-                const long long gk = s_bk[par][wb];
-                const int gp = s_bpz[par][wb];
-                long long gx = s_bx[par][wb];
-                for (int k = 0; k < NW; k++)
-                    if (k != wb && s_bk[par][k] < gx) gx = s_bk[par][k];
-                if (gp != INT_MAX) {
-                    const int t1 = gp / E;
-                    int ch = t1 + rot;
-                    if (ch >= nchunks) ch -= nchunks;
-                    const int j1 = ch * E + (gp - t1 * E);
-                    const long long inc = (gx == (long long)Tr<CT>::KMAX) ? 0 : ((gx >> 1) - (gk >> 1));
-                    if (j1 < n) atomicMax(&bid[j1], ((unsigned long long)inc << ROW_BITS) | (unsigned long long)(grow + 1));
-                }
-            }
-        }
     }
 }
 
@@ -2407,54 +2319,6 @@ __global__ void k_fill_i32(int *p, int count, int v)
     if (i < count) p[i] = v;
 }
 
-// After the eps > 0 warm start: keep exactly the assigned pairs that are TIGHT at the warmed prices
-// (c'_ij + p_j == min_k (c'_ik + p_k)), free the others. Any price vector is dual feasible, and
-// tight pairs satisfy exact complementary slackness, so the eps = 0 rounds and the shortest
-// augmenting paths continue from a state that already holds most of the matching and whose
-// remaining paths are short. One wave per row; a column has at most one owner, so freeing it
-// races with nobody (other waves only read the price bits of pk[j]).
-template <typename CT>
-__global__ __launch_bounds__(256) void k_keep_tight(int n, int nrows, int row0, int nchunks, const CT *__restrict__ cc,
-                                                    typename Tr<CT>::PT *pk, int *__restrict__ owner,
-                                                    int *__restrict__ r2c, int *__restrict__ ctl)
-{
-    using PT = typename Tr<CT>::PT;
-    constexpr int E = Tr<CT>::E;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const size_t pitch = (size_t)nchunks * E;
-    if (blockIdx.x == 0)
-        for (int j = CTL_PROG + threadIdx.x; j < CTL_WORDS; j += blockDim.x) ctl[j] = 0;
-    for (int row = blockIdx.x * nw + w; row < nrows; row += gridDim.x * nw) {
-        const int j0 = r2c[row];
-        if (j0 < 0) continue;   // free (or deferred) already
-        const CT *rp = cc + (size_t)row * pitch;
-        PT m = Tr<CT>::KMAX;
-        for (int ch = lane; ch < nchunks; ch += 64) {
-            const uint4 cv = *reinterpret_cast<const uint4 *>(rp + (size_t)ch * E);
-            uint32_t c[E];
-            unpack<CT>(cv, c);
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                const PT v = (PT)c[e] + (pk[(size_t)ch * E + e] >> 1);
-                m = v < m ? v : m;
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            PT om = shfl_xor_t(m, o);
-            m = om < m ? om : m;
-        }
-        if (lane == 0) {
-            const PT mine = (PT)rp[j0] + (pk[j0] >> 1);
-            if (mine != m) {
-                r2c[row] = -1;
-                owner[j0] = -1;
-                pk[j0] = (PT)((pk[j0] >> 1) << 1);   // no owner any more
-            }
-        }
-    }
-}
-
 // dual bound D = sum_i (rowmin_i + min_j (c'_ij + p_j)) - sum_j p_j ; one wave per (local) row
 template <typename CT>
 __global__ __launch_bounds__(256) void k_dual(int n, int nrows, int row0, int nchunks, const CT *__restrict__ cc,
@@ -2507,7 +2371,8 @@ __global__ __launch_bounds__(256) void k_dual(int n, int nrows, int row0, int nc
 struct td_shard {
     int n = 0, row0 = 0, nrows = 0;
     int bpc = 0;  // bytes per stored cell: 1, 2, 4 (0 = not compressed yet)
-    bool fused_bid0 = false;  // the compress pass already published bidding round 0
+    int64_t range = 0;      // largest row range of this shard, exact once a compress pass at a narrower width has failed
+    int64_t fit_bound = -1;  // else: the limit of the narrowest width the rows have fitted so far
     int nchunks = 0, npad = 0;
     const int32_t *d_cost = nullptr;  // nrows x n, device
     Buf stage, cc, price, owner, r2c, r2c_full, bid, pred, list, rowmin, rconst, misc, psrec, tbuf, xbuf;
@@ -2561,7 +2426,7 @@ int sv_prepare(Solver &sv, int n, int row0, int nrows, const int32_t *cost)
 }
 
 template <typename CT>
-int sv_compress_t(Solver &sv, bool *fits, bool speculate = false, bool bid0 = false)
+int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
 {
     Ctx &c = ctx();
     constexpr int E = Tr<CT>::E;
@@ -2573,7 +2438,6 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false, bool bid0 = fa
     TD_HIP(hipMemsetAsync(ctl, 0, CTL_ALL * sizeof(int), c.stream));  // flag, error, stats, range, shape
     const bool vec = (n % 4 == 0) && (((uintptr_t)sv.d_cost & 15) == 0);
     const int grid = std::max(1, std::min(nrows, c.n_cu * 8));
-    sv.fused_bid0 = false;
     if (nrows > 0) {
         ProfScope ps(TD_K_COMPRESS);
         const int nq = n / 4;
@@ -2582,19 +2446,13 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false, bool bid0 = fa
         int *rcs = (int *)sv.rconst.p;
         if (g_creg && vec && nq <= 256 * 16) {
             const int g2 = std::max(1, std::min(nrows, c.n_cu * g_cgrid));
-#define TD_CR(VPT)                                                                                                          \
-    if (bid0)                                                                                                          \
-        k_compress_reg<CT, VPT, 256, true><<<g2, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs,  \
-                                                                    (unsigned long long *)sv.bid.p, sv.row0);          \
-    else                                                                                                               \
-        k_compress_reg<CT, VPT, 256><<<g2, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs)
+#define TD_CR(VPT) k_compress_reg<CT, VPT, 256><<<g2, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs)
             if (nq <= 256) { TD_CR(1); }
             else if (nq <= 512) { TD_CR(2); }
             else if (nq <= 1024) { TD_CR(4); }
             else if (nq <= 2048) { TD_CR(8); }
             else { TD_CR(16); }
 #undef TD_CR
-            sv.fused_bid0 = bid0;
         } else if (g_creg && vec && nq <= 1024 * 16) {
             k_compress_reg<CT, 16, 1024><<<std::max(1, std::min(nrows, c.n_cu * 2)), 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs);
         } else if (vec)
@@ -2623,10 +2481,10 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false, bool bid0 = fa
     return TD_OK;
 }
 
-int sv_compress(Solver &sv, int bpc, bool *fits, bool speculate = false, bool bid0 = false)
+int sv_compress(Solver &sv, int bpc, bool *fits, bool speculate = false)
 {
     switch (bpc) {
-        case 1: return sv_compress_t<uint8_t>(sv, fits, speculate, bid0);
+        case 1: return sv_compress_t<uint8_t>(sv, fits, speculate);
         case 2: return sv_compress_t<uint16_t>(sv, fits, speculate);
         case 4: return sv_compress_t<uint32_t>(sv, fits, speculate);
     }
@@ -2707,13 +2565,6 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
     const int n = sv.n, nchunks = sv.nchunks, npad = sv.npad;
     int CH = 1;
     while (CH * 1024 < nchunks) CH *= 2;
-    // small models: prefer ONE wavefront that owns several chunks per lane over two or four
-    // wavefronts with one chunk each — a single wave needs no barrier / LDS exchange per step
-    if (g_onewave && sizeof(CT) > 1) {
-        int ch1 = 1;
-        while (ch1 * 64 < nchunks) ch1 *= 2;
-        if (ch1 * E <= g_onewave && ch1 <= 16) CH = ch1;
-    }
     int T = (nchunks + CH - 1) / CH;
     T = std::min(1024, std::max(64, ((T + 63) / 64) * 64));
     const size_t st = (size_t)npad * 2 * sizeof(int);  // owner[] + pred[]
@@ -2724,7 +2575,7 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
     k_freelist<<<1, 1024, 0, ctx().stream>>>(n, r2c_full, (int *)sv.list.p, (int *)sv.misc.p);
     // ---- speculative parallel searches first (a few batches), the serial workgroup mops up
     // (u8 instances go straight to the lean tie-batching serial workgroup, which is faster there)
-    if (g_psap_batches > 0 && CH <= 4 && CH * E <= 16 && lds && n >= 64 && (sizeof(CT) > 1 || g_psap_u8)) {
+    if (g_psap_batches > 0 && CH <= 4 && CH * E <= 16 && lds && n >= 64 && sizeof(CT) > 1) {
         Ctx &c = ctx();
         using PT = typename Tr<CT>::PT;
         int rc = ensure(sv.psrec, sizeof(PsRec<PT>) * (size_t)PS_G);
@@ -2783,27 +2634,34 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
             if (!worth) break;
         }
     }
-    {   // cooperative finisher: the columns of one search split over several CUs
-        // 256-thread workgroups by default. One wavefront per workgroup on up to 64 CUs (TD_SAPX_T=64)
-        // was measured slower: the time per published row does not shrink with the segment a CU
-        // loads (0.15 us either way), while twice as many rows are published per step
-        const int TXsel = (g_sapx_t == 64 && (nchunks + 63) / 64 <= SX_KMAX) ? 64 : 256;
+    {   // cooperative finisher: the columns of one search split over several CUs, 256-thread
+        // workgroups.  Launched with hipLaunchCooperativeKernel: its grid barrier needs every
+        // workgroup resident at the same time, which an ordinary launch does not promise when other
+        // streams or processes share the GPU.  If the cooperative launch is refused the
+        // single-workgroup finisher below does the job.
+        constexpr int TXsel = 256;
         const int KX = (nchunks + TXsel - 1) / TXsel;
         const bool lean8 = sizeof(CT) == 1 && CH == 1 && g_sap8;
+        bool launched_x = false;
         if (g_sapx && !lean8 && KX * TXsel >= g_sapx_min * 256 && KX <= SX_KMAX) {
             Ctx &c = ctx();
             using PT = typename Tr<CT>::PT;
             int rc = ensure(sv.xbuf, sizeof(SxShared));
             if (rc) return rc;
             TD_HIP(hipMemsetAsync(sv.xbuf.p, 0, 64, c.stream));   // barrier counter, abort flag, debug counters
-            if (TXsel == 64)
-                k_sapx<CT, 64><<<KX, 64, 0, c.stream>>>(n, nchunks, tab, (PT *)sv.price.p, (int *)sv.owner.p, r2c_full,
-                                                        (int *)sv.pred.p, (const int *)sv.list.p, (int *)sv.misc.p,
-                                                        (SxShared *)sv.xbuf.p);
-            else
-                k_sapx<CT, 256><<<KX, 256, 0, c.stream>>>(n, nchunks, tab, (PT *)sv.price.p, (int *)sv.owner.p, r2c_full,
-                                                          (int *)sv.pred.p, (const int *)sv.list.p, (int *)sv.misc.p,
-                                                          (SxShared *)sv.xbuf.p);
+            int a_n = n, a_nch = nchunks;
+            ShardTab a_tab = tab;
+            PT *a_pk = (PT *)sv.price.p;
+            int *a_owner = (int *)sv.owner.p, *a_r2c = r2c_full, *a_pred = (int *)sv.pred.p, *a_ctl = (int *)sv.misc.p;
+            const int *a_list = (const int *)sv.list.p;
+            SxShared *a_sh = (SxShared *)sv.xbuf.p;
+            void *kargs[] = {&a_n, &a_nch, &a_tab, &a_pk, &a_owner, &a_r2c, &a_pred, &a_list, &a_ctl, &a_sh};
+            const hipError_t le = hipLaunchCooperativeKernel((const void *)k_sapx<CT, 256>, dim3(KX), dim3(TXsel), kargs, 0, c.stream);
+            if (le == hipSuccess) launched_x = true;
+            else (void)hipGetLastError();
+        }
+        if (launched_x) {
+            Ctx &c = ctx();
             TD_HIP(hipGetLastError());
             if (getenv("TD_DEBUG")) {
                 long long dbg[8];
@@ -2859,7 +2717,7 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
         int ch5 = 1;
         while (ch5 * 512 < nchunks) ch5 *= 2;
         // (measured: only a win when the workgroup has <= 512 threads anyway, i.e. no wave is given up)
-        if (g_sap512 && ch5 == CH && ch5 * E <= 16 && !(g_onewave && CH * E <= g_onewave)) {
+        if (g_sap512 && ch5 == CH && ch5 * E <= 16) {
             int T5 = (nchunks + ch5 - 1) / ch5;
             T5 = std::min(512, std::max(64, ((T5 + 63) / 64) * 64));
 #define TD_SAP5(CHV)                                                               \
@@ -2993,13 +2851,9 @@ int sv_warm_t(Solver &sv, int64_t range, int64_t *rounds_out)
         }
         if (eps <= eps_last) break;
     }
-    // keep the prices and the pairs that are exactly tight at them, free the rest
-    if (g_warm_keep)
-        k_keep_tight<CT><<<std::max(1, std::min((sv.nrows + 3) / 4, c.n_cu * 8)), 256, 0, c.stream>>>(
-            n, sv.nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (PT *)sv.price.p, (int *)sv.owner.p, (int *)sv.r2c.p, (int *)sv.misc.p);
-    else
-        k_eps_reset<PT><<<(std::max(n, (int)CTL_WORDS) + 255) / 256, 256, 0, c.stream>>>(n, sv.nrows, (PT *)sv.price.p, (int *)sv.owner.p,
-                                                                                       (int *)sv.r2c.p, (int *)sv.misc.p);
+    // only the prices are kept
+    k_eps_reset<PT><<<(std::max(n, (int)CTL_WORDS) + 255) / 256, 256, 0, c.stream>>>(n, sv.nrows, (PT *)sv.price.p, (int *)sv.owner.p,
+                                                                                   (int *)sv.r2c.p, (int *)sv.misc.p);
     TD_HIP(hipGetLastError());
     *rounds_out = rounds;
     return TD_OK;
@@ -3325,28 +3179,17 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
                         (long long)known_range, n);
         // u8 is tried speculatively (no host round trip in the common case)
         const bool spec = (bpc == 1) && g_speculate;
-        const bool fuse0 = spec && g_fuse_bid0 && g_creg && (n % 4 == 0) && n / 4 <= 256 * 16 && (((uintptr_t)sv.d_cost & 15) == 0);
-        if (fuse0) {  // state (zero bids, zero prices) must exist before the fused pass publishes bids
-            constexpr int E8 = Tr<uint8_t>::E;
-            sv.bpc = 1;
-            sv.nchunks = (n + E8 - 1) / E8;
-            sv.npad = sv.nchunks * E8;
-            rc = sv_begin_t<uint8_t>(sv);
-            if (rc) return rc;
-        }
-        if ((rc = sv_compress(sv, bpc, &fits, spec, fuse0))) return rc;
+        if ((rc = sv_compress(sv, bpc, &fits, spec))) return rc;
         if (!fits) {
             known_range = c.stats[6];
             continue;
         }
         // shape probe (inside k_init_state): may ask (CTL_FLAG bit 2) for the transposed formulation;
         // like a failed width speculation this costs one empty pass through the early-exiting kernels
-        sv.probe = (spec && orient == 0 && g_shape && n >= 64 && n <= g_shape_max_n && !g_solver_eps && !fuse0) ? sv.d_cost : nullptr;
-        if (!fuse0) {
-            TD_DISPATCH(sv, sv_begin_t, sv);
-            sv.probe = nullptr;
-            if (rc) return rc;
-        }
+        sv.probe = (spec && orient == 0 && g_shape && n >= 64 && n <= g_shape_max_n && !g_solver_eps) ? sv.d_cost : nullptr;
+        TD_DISPATCH(sv, sv_begin_t, sv);
+        sv.probe = nullptr;
+        if (rc) return rc;
         int64_t warm_rounds = 0;
         bool core_done = false, core_partial = false;
         for (int q = 8; q < 16; q++) c.stats[q] = 0;
@@ -3368,12 +3211,10 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
             solved = true;
             break;
         }
-        auto rounds = [&](bool first) -> int {
+        auto rounds = [&](bool) -> int {
             for (int r = 0; r < max_rounds; r++) {
-                if (!(r == 0 && sv.fused_bid0 && first)) {
-                    TD_DISPATCH(sv, sv_bid_t, sv, r, (unsigned long long *)sv.bid.p);
-                    if (rc) return rc;
-                }
+                TD_DISPATCH(sv, sv_bid_t, sv, r, (unsigned long long *)sv.bid.p);
+                if (rc) return rc;
                 TD_DISPATCH(sv, sv_apply_t, sv, r, (unsigned long long *)sv.bid.p);
                 if (rc) return rc;
             }
@@ -3534,13 +3375,32 @@ int td_shard_compress(td_shard *s, int bytes_per_cell, int *fits)
     bool f = false;
     int rc = sv_compress(*s, bytes_per_cell, &f);
     *fits = f ? 1 : 0;
+    // a failed pass records the largest row range exactly; a pass that fits bounds it by the width
+    if (!rc && !f) s->range = std::max<int64_t>(s->range, ctx().stats[6]);
+    if (!rc && f) {
+        const int64_t lim = bytes_per_cell == 1 ? 254 : (bytes_per_cell == 2 ? 65534 : 0xFFFFFFFEll);
+        s->fit_bound = s->fit_bound < 0 ? lim : std::min(s->fit_bound, lim);
+    }
     return rc;
 }
 
-int td_shard_begin(td_shard *s)
+int td_shard_range(td_shard *s, int64_t *range)
+{
+    TD_REQUIRE_INIT();
+    if (!s || !range) return fail(TD_EINVAL, "null argument");
+    *range = s->range > 0 ? s->range : std::max<int64_t>(0, s->fit_bound);
+    return TD_OK;
+}
+
+int td_shard_begin(td_shard *s, int64_t global_range)
 {
     TD_REQUIRE_INIT();
     if (!s) return fail(TD_EINVAL, "null shard");
+    const int64_t range = global_range >= 0 ? global_range : (s->range > 0 ? s->range : std::max<int64_t>(0, s->fit_bound));
+    // same guard as td_assign: the packed bid key keeps (price << 20 | row), prices stay below n * range;
+    // the keys also travel through a signed 64-bit MAX all-reduce
+    if ((double)(range + 1) * (double)(s->n + 1) >= 4.0e12)
+        return fail(TD_ERANGE, "row cost range %lld with n=%d overflows the packed bid key (price < 2^43)", (long long)range, s->n);
     int rc;
     TD_DISPATCH(*s, sv_begin_t, *s);
     return rc;

@@ -91,7 +91,10 @@ void prof_begin(int k)
     if (!c.prof) return;
     if (c.n_pend >= 4096) prof_flush();
     hipEvent_t a = next_event(), b = next_event();
-    if (!a || !b) return;
+    if (!a || !b) {
+        c.pend[c.n_pend].k = -1;   // no event left: prof_end must not match a stale entry
+        return;
+    }
     c.pend[c.n_pend] = {a, b, k};
     (void)hipEventRecord(a, c.stream);
 }
@@ -139,7 +142,8 @@ __global__ __launch_bounds__(256) void k_cost_build(const int32_t *__restrict__ 
                                                     const int32_t *__restrict__ dem_from,
                                                     const int32_t *__restrict__ dem_id, int n_d,
                                                     const int32_t *__restrict__ dist, int S, int32_t fill,
-                                                    int32_t thr, int n, int32_t *__restrict__ cost)
+                                                    int32_t thr, int n, int row0, int nrows,
+                                                    int32_t *__restrict__ cost /* rows [row0, row0 + nrows) */)
 {
     extern __shared__ int32_t s_dist[];
     if (LDS_DIST) {
@@ -159,7 +163,8 @@ __global__ __launch_bounds__(256) void k_cost_build(const int32_t *__restrict__ 
         b[e] = bv[e] ? dem_from[d] : 0;
         if (dist && (uint32_t)b[e] >= (uint32_t)S) bv[e] = false;  // never index outside the table
     }
-    for (int r = blockIdx.y; r < n; r += gridDim.y) {
+    for (int rr = blockIdx.y; rr < nrows; rr += gridDim.y) {
+        const int r = row0 + rr;
         int32_t v[4] = {fill, fill, fill, fill};
         bool rv = r < n_s && (!cab_id || cab_id[r] != -1);
         const int32_t a = rv ? cab_to[r] : 0;
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256) void k_cost_build(const int32_t *__restrict__ 
                 }
             }
         }
-        int32_t *dst = cost + (int64_t)r * n + d0;
+        int32_t *dst = cost + (int64_t)rr * n + d0;
         if (VEC4) {
             *reinterpret_cast<int4 *>(dst) = make_int4(v[0], v[1], v[2], v[3]);
         } else {
@@ -195,13 +200,14 @@ __global__ void k_fill_i32(int32_t *p, int64_t count, int32_t v)
 // procedure.py:9-12 — cells addressed by id
 __global__ void k_cost_scatter_by_id(const int32_t *cab_to, const int32_t *cab_id, int n_s,
                                      const int32_t *dem_from, const int32_t *dem_id, int n_d,
-                                     const int32_t *dist, int S, int32_t thr, int n, int32_t *cost)
+                                     const int32_t *dist, int S, int32_t thr, int n, int row0, int nrows, int32_t *cost)
 {
     int d = blockIdx.x * blockDim.x + threadIdx.x;
     int c = blockIdx.y;
     if (d >= n_d || c >= n_s) return;
     int ci = cab_id[c], di = dem_id[d];
-    if (ci < 0 || ci >= n || di < 0 || di >= n) return;
+    if (ci < row0 || ci >= row0 + nrows || ci >= n || di < 0 || di >= n) return;
+    ci -= row0;
     int a = cab_to[c], b = dem_from[d];
     if (dist && ((uint32_t)a >= (uint32_t)S || (uint32_t)b >= (uint32_t)S)) return;
     int32_t x = dist ? dist[(int64_t)a * S + b] : (a > b ? a - b : b - a);
@@ -391,15 +397,18 @@ int td_last_stats(int64_t *out, int n)
     return TD_OK;
 }
 
-int td_cost_build(const int32_t *cab_to, const int32_t *cab_id, int n_s, const int32_t *dem_from,
-                  const int32_t *dem_id, int n_d, const int32_t *dist, int S, int32_t fill, int32_t threshold,
-                  int by_id, int32_t *cost)
+static int cost_build_impl(const int32_t *cab_to, const int32_t *cab_id, int n_s, const int32_t *dem_from,
+                           const int32_t *dem_id, int n_d, const int32_t *dist, int S, int32_t fill, int32_t threshold,
+                           int by_id, int row0, int nrows, int32_t *cost)
 {
     TD_REQUIRE_INIT();
     Ctx &c = ctx();
     if (n_s < 0 || n_d < 0) return fail(TD_EINVAL, "negative sizes n_s=%d n_d=%d", n_s, n_d);
     const int n = std::max(n_s, n_d);
     if (n == 0) return TD_OK;  // simulate.py:21 / Simulator.java:499: empty model
+    if (nrows < 0) nrows = n;   // the whole matrix
+    if (row0 < 0 || row0 + nrows > n) return fail(TD_EINVAL, "row window [%d, %d) outside the %d x %d model", row0, row0 + nrows, n, n);
+    if (nrows == 0) return TD_OK;
     if (!cost || (n_s && !cab_to) || (n_d && !dem_from)) return fail(TD_EINVAL, "null array");
     if (dist && S <= 0) return fail(TD_EINVAL, "dist given but S=%d", S);
     if (by_id && (!cab_id || !dem_id)) return fail(TD_EINVAL, "by_id needs cab_id and dem_id");
@@ -431,7 +440,7 @@ int td_cost_build(const int32_t *cab_to, const int32_t *cab_id, int n_s, const i
     }
     const bool out_dev = is_device_ptr(cost);
     int32_t *d_cost = cost;
-    const size_t cbytes = sizeof(int32_t) * (size_t)n * n;
+    const size_t cbytes = sizeof(int32_t) * (size_t)nrows * n;
     if (!out_dev) {
         if ((rc = ensure(c.stage_out, cbytes))) return rc;
         d_cost = (int32_t *)c.stage_out.p;
@@ -439,12 +448,12 @@ int td_cost_build(const int32_t *cab_to, const int32_t *cab_id, int n_s, const i
     {
         ProfScope ps(TD_K_COST_BUILD);
         if (by_id) {
-            k_fill_i32<<<std::min<int64_t>(((int64_t)n * n + 255) / 256, 8192), 256, 0, c.stream>>>(d_cost, (int64_t)n * n, fill);
+            k_fill_i32<<<std::min<int64_t>(((int64_t)nrows * n + 255) / 256, 8192), 256, 0, c.stream>>>(d_cost, (int64_t)nrows * n, fill);
             if (n_s && n_d) {
                 dim3 g((n_d + 255) / 256, n_s);
                 k_cost_scatter_by_id<<<g, 256, 0, c.stream>>>((const int32_t *)d_cab, (const int32_t *)d_cid, n_s,
                                                               (const int32_t *)d_dem, (const int32_t *)d_did, n_d,
-                                                              (const int32_t *)d_dist, S, threshold, n, d_cost);
+                                                              (const int32_t *)d_dist, S, threshold, n, row0, nrows, d_cost);
             }
         } else {
             const int nq = (n + 3) / 4;
@@ -453,12 +462,12 @@ int td_cost_build(const int32_t *cab_to, const int32_t *cab_id, int n_s, const i
             const size_t shm = lds ? (size_t)S * S * 4 : 0;
             // rows per block column: enough workgroups to fill 256 CUs several times over
             int gx = (nq + 255) / 256;
-            int gy = std::min(n, std::max(1, (c.n_cu * 16) / gx));
+            int gy = std::min(nrows, std::max(1, (c.n_cu * 16) / gx));
             dim3 g(gx, gy);
 #define TD_LAUNCH_CB(V, L)                                                                                            \
     k_cost_build<V, L><<<g, 256, shm, c.stream>>>((const int32_t *)d_cab, (const int32_t *)d_cid, n_s,               \
                                                   (const int32_t *)d_dem, (const int32_t *)d_did, n_d,               \
-                                                  (const int32_t *)d_dist, S, fill, threshold, n, d_cost)
+                                                  (const int32_t *)d_dist, S, fill, threshold, n, row0, nrows, d_cost)
             if (vec && lds) TD_LAUNCH_CB(true, true);
             else if (vec) TD_LAUNCH_CB(true, false);
             else if (lds) TD_LAUNCH_CB(false, true);
@@ -472,6 +481,21 @@ int td_cost_build(const int32_t *cab_to, const int32_t *cab_id, int n_s, const i
     }
     TD_HIP(hipStreamSynchronize(c.stream));
     return TD_OK;
+}
+
+int td_cost_build(const int32_t *cab_to, const int32_t *cab_id, int n_s, const int32_t *dem_from,
+                  const int32_t *dem_id, int n_d, const int32_t *dist, int S, int32_t fill, int32_t threshold,
+                  int by_id, int32_t *cost)
+{
+    return cost_build_impl(cab_to, cab_id, n_s, dem_from, dem_id, n_d, dist, S, fill, threshold, by_id, 0, -1, cost);
+}
+
+int td_cost_build_rows(const int32_t *cab_to, const int32_t *cab_id, int n_s, const int32_t *dem_from,
+                       const int32_t *dem_id, int n_d, const int32_t *dist, int S, int32_t fill, int32_t threshold,
+                       int by_id, int row0, int nrows, int32_t *cost_rows)
+{
+    if (nrows < 0) return fail(TD_EINVAL, "nrows < 0");
+    return cost_build_impl(cab_to, cab_id, n_s, dem_from, dem_id, n_d, dist, S, fill, threshold, by_id, row0, nrows, cost_rows);
 }
 
 int td_gen_uniform(int n, uint64_t seed, int32_t lo, int32_t hi, int row0, int nrows, int32_t *cost)

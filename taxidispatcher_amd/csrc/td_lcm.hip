@@ -640,7 +640,18 @@ namespace {
 
 __device__ __forceinline__ int pool_d(const int32_t *dist, int S, int a, int b)
 {
-    return dist ? dist[(int64_t)a * S + b] : (a > b ? a - b : b - a);
+    if (!dist) return a > b ? a - b : b - a;
+    // never index outside the table: stands outside [0, S) are reported by k_pool2_check (TD_EINVAL)
+    a = min(max(a, 0), S - 1);
+    b = min(max(b, 0), S - 1);
+    return dist[(int64_t)a * S + b];
+}
+
+// with a distance table every from / to must be a stand of the table
+__global__ void k_pool2_check(int n, const int32_t *__restrict__ from, const int32_t *__restrict__ to, int S, int *flag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && ((uint32_t)from[i] >= (uint32_t)S || (uint32_t)to[i] >= (uint32_t)S)) atomicOr(flag, 1);
 }
 
 // pair cost matrix: pc[A][B] = min(cost1, cost2), diagonal = INT_MAX (never a candidate)
@@ -717,6 +728,9 @@ extern "C" int td_pool2(int n, const int32_t *from, const int32_t *to, const int
     const size_t shm_mask = sizeof(uint32_t) * (size_t)((n + 31) / 32);
     {
         ProfScope ps(TD_K_LCM);
+        TD_HIP(hipMemsetAsync((char *)c.lcm_d.p + 192, 0, sizeof(int), c.stream));
+        if (d_dist)
+            k_pool2_check<<<(n + 255) / 256, 256, 0, c.stream>>>(n, (const int32_t *)d_from, (const int32_t *)d_to, S, (int *)((char *)c.lcm_d.p + 192));
         dim3 g((n + 255) / 256, std::min(n, 1024));
         k_pool2_cost<<<g, 256, 0, c.stream>>>(n, (const int32_t *)d_from, (const int32_t *)d_to, (const int32_t *)d_dist, S, pc);
         TD_HIP(hipMemsetD32Async((hipDeviceptr_t)d_base, INT_MAX, 1, c.stream));
@@ -732,8 +746,9 @@ extern "C" int td_pool2(int n, const int32_t *from, const int32_t *to, const int
                                             narrow ? (const uint8_t *)c.cc.p : nullptr, pitch, d_base, 1);
     }
     TD_HIP(hipGetLastError());
-    TD_HIP(hipMemcpyAsync(c.pinned, c.lcm_d.p, sizeof(LcmOut), hipMemcpyDeviceToHost, c.stream));
+    TD_HIP(hipMemcpyAsync(c.pinned, c.lcm_d.p, 256, hipMemcpyDeviceToHost, c.stream));
     TD_HIP(hipStreamSynchronize(c.stream));
+    if (*(const int *)((const char *)c.pinned + 192)) return fail(TD_EINVAL, "td_pool2: a from / to stand lies outside the %d x %d distance table", S, S);
     const int k = ((const LcmOut *)c.pinned)->n_pairs;
     if (k > 0) {
         k_pool2_plans<<<(k + 255) / 256, 256, 0, c.stream>>>(k, n, (const int32_t *)d_from, (const int32_t *)d_to,

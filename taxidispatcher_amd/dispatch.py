@@ -229,7 +229,10 @@ def count_sum(nn, cost, res, big_cost=BIG_COST):
     dist[supply[taxi].to][demand[trip].from] for every real cell, the sum over x==1 cells with
     cost < big_cost equals the reference's sum of dist[...] terms. `res` is x (n*n) or row_to_col."""
     res = np.asarray(res)
-    if res.size == nn * nn and nn != 1:
+    if nn == 1:
+        # x = [1] and row_to_col = [0] have the same size: with one row the only assignment is column 0
+        r2c = np.zeros(1, np.int32)
+    elif res.size == nn * nn:
         r2c = np.full(nn, -1, np.int32)
         ii, jj = np.nonzero(res.reshape(nn, nn) == 1)
         r2c[ii] = jj

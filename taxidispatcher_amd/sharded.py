@@ -41,11 +41,17 @@ class HipShard:
         import torch
         self.torch = torch
         self.lib = _ffi.lib()
-        # Run the library on torch's current stream: RCCL collectives are ordered with that stream,
-        # so bid -> all_reduce -> apply needs no host synchronisation at all.
+        # Run the library AND the collectives on one dedicated, non-null torch stream: RCCL orders
+        # its collectives with torch's current stream, so bid -> all_reduce -> apply needs no host
+        # synchronisation.  (torch's default stream has handle 0, which td_set_stream reads as
+        # "use the library's own stream": sharing it would leave kernels and collectives unordered.)
         self.shared_stream = bool(share_torch_stream)
+        self.stream = None
         if self.shared_stream:
-            _ffi.check(self.lib.td_set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            self.stream = torch.cuda.Stream()
+            self.stream.wait_stream(torch.cuda.current_stream())   # inputs written on the caller's stream
+            assert self.stream.cuda_stream != 0
+            _ffi.check(self.lib.td_set_stream(ctypes.c_void_p(self.stream.cuda_stream)))
         self.n, self.row0, self.nrows = n, row0, nrows
         self._cost = cost_rows  # keep alive: the library reads it again for the total
         h = ctypes.c_void_p()
@@ -55,6 +61,11 @@ class HipShard:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self._opened = []
 
+    def stream_ctx(self):
+        """context in which solve_sharded issues its collectives and tensor ops"""
+        import contextlib
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def close(self):
         for p in self._opened:
             self.lib.td_ipc_close(ctypes.c_void_p(p))
@@ -62,6 +73,10 @@ class HipShard:
         if self.h:
             self.lib.td_shard_destroy(self.h)
             self.h = None
+        if self.stream is not None:
+            self.stream.synchronize()
+            self.lib.td_set_stream(None)   # back to the library's own stream
+            self.stream = None
 
     # -- compression width agreement
     def compress(self, bytes_per_cell):
@@ -69,8 +84,13 @@ class HipShard:
         _ffi.check(self.lib.td_shard_compress(self.h, bytes_per_cell, ctypes.byref(fits)))
         return bool(fits.value)
 
-    def begin(self):
-        _ffi.check(self.lib.td_shard_begin(self.h))
+    def range(self):
+        r = ctypes.c_int64(0)
+        _ffi.check(self.lib.td_shard_range(self.h, ctypes.byref(r)))
+        return int(r.value)
+
+    def begin(self, global_range=-1):
+        _ffi.check(self.lib.td_shard_begin(self.h, int(global_range)))
 
     def new_keys(self):
         return self.torch.zeros(self.lib.td_shard_keys_len(self.h) + 16, dtype=self.torch.int64, device=self.device)
@@ -218,6 +238,14 @@ def all_gather_equal(dist, t):
 def solve_sharded(shard, dist, rounds=DEFAULT_ROUNDS, want_dual=False, use_ipc=None):
     """Collective part of the sharded solve; `shard` implements the HipShard interface and `dist`
     is torch.distributed (initialised). Returns (local row_to_col, total[, dual])."""
+    ctx = shard.stream_ctx() if hasattr(shard, "stream_ctx") else None
+    if ctx is None:
+        return _solve_sharded(shard, dist, rounds, want_dual, use_ipc)
+    with ctx:
+        return _solve_sharded(shard, dist, rounds, want_dual, use_ipc)
+
+
+def _solve_sharded(shard, dist, rounds, want_dual, use_ipc):
     global _NEED_FENCE
     world, rank = dist.get_world_size(), dist.get_rank()
     n = shard.n
@@ -233,7 +261,14 @@ def solve_sharded(shard, dist, rounds=DEFAULT_ROUNDS, want_dual=False, use_ipc=N
             break
     else:
         raise _ffi.TdError("row cost range exceeds 2^32-2 on some rank")
-    shard.begin()
+    # the packed-key range guard needs the largest row range of ANY rank (td_assign's TD_ERANGE rule)
+    grange = -1
+    if hasattr(shard, "range"):
+        rt = shard.scalar_tensor([shard.range()])
+        if world > 1:
+            all_reduce(dist, rt, MAX)
+        grange = int(rt[0].item())
+    shard.begin(grange)
     # 2. Jacobi bidding rounds: ONE exchange step per round
     keys = shard.new_keys()
     for r in range(rounds):

@@ -32,7 +32,7 @@ class ModelShard:
         self.cc = self.cost - self.rowmin[:, None]
         return True
 
-    def begin(self):
+    def begin(self, global_range=-1):
         self.p = np.zeros(self.n, np.int64)
         self.owner = np.full(self.n, -1, np.int64)
         self.r2c = np.full(self.nrows, -1, np.int64)

@@ -214,3 +214,39 @@ def test_statistical_kat_combined_method():
         sizes.append(n2)
     assert 0.5 < float(np.mean(gaps)) < 5.0
     assert 125 < float(np.mean(sizes)) < 170
+
+
+def test_oracle_under_address_sanitizer():
+    """`make -C oracle asan` + a run of the oracle's entry points under ASan/UBSan in a child process
+    (the GPU side cannot be sanitised on this pool, the CPU checker can)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "asan"])
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    ubsan = subprocess.check_output(["gcc", "-print-file-name=libubsan.so"], text=True).strip()
+    code = r'''
+import numpy as np, os, sys
+sys.path.insert(0, %r)
+from oracle import oracle
+oracle._LIB = os.path.join(%r, "oracle", "_build", "liboracle_asan.so")
+oracle._lib = None
+import ctypes
+oracle.build = lambda force=False: oracle._LIB
+rng = np.random.default_rng(0)
+for n in (1, 2, 7, 64, 130):
+    c = rng.integers(0, 50, (n, n)).astype(np.int32)
+    t, r2c, u, v = oracle.assign(c)
+    assert sorted(r2c.tolist()) == list(range(n)) and t == int(c[np.arange(n), r2c].sum())
+    oracle.is_unique(c, r2c, u, v)
+    oracle.lcm(c, mask=250000, threshold=10, sum_below=250000)
+    oracle.lcm(c, mask=250000, stop_value_on=1, stop_value=250000, stop_size=max(0, n - 3), sum_below=250000, java_scan=1)
+n, cost = oracle.cost_build(rng.integers(0, 50, 33), rng.integers(0, 50, 21), None, 250000, 10)
+oracle.cost_build(rng.integers(0, 9, 5), rng.integers(0, 9, 8), rng.integers(0, 9, (9, 9)).astype(np.int32), 250000, -1)
+oracle.gen_uniform(37, 3, 10, 40)
+print("asan ok")
+''' % (root, root)
+    env = dict(os.environ, LD_PRELOAD=asan + ":" + ubsan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "asan ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
