@@ -143,7 +143,7 @@ TD_API int td_gen_uniform(int n, uint64_t seed, int32_t lo, int32_t hi, int row0
  * One process per GPU.  Rank r owns cost rows [row0, row0+nrows) x all n columns; prices and
  * column owners are replicated.  The exchange step between ranks (one MAX all-reduce of the
  * packed 64-bit bid keys per bidding round) is done by the CALLER with torch.distributed /
- * RCCL on the key buffer — the library never links a collective.  Host driver:
+ * RCCL on the key buffer, or by the library itself (td_shard_rounds below).  Host driver:
  * taxidispatcher_amd/sharded.py.
  *   td_shard_compress   narrow working copy of the local rows (1, 2 or 4 bytes per cell); every
  *                       rank must end up with the same width (caller reduces `fits` with MIN)
@@ -169,6 +169,14 @@ TD_API int td_shard_keys_len(td_shard *s);
 TD_API int td_shard_bid(td_shard *s, int round, uint64_t *keys);
 TD_API int td_shard_apply(td_shard *s, int round, uint64_t *keys);
 TD_API int td_shard_cc(td_shard *s, void **ptr, uint64_t *bytes);
+/* All bidding rounds in ONE call: per round  td_shard_bid -> RCCL MAX all-reduce of the keys -> td_shard_apply,
+ * enqueued back to back on the library's stream (no host work between the rounds).  The communicator is
+ * the library's own: rank 0 makes a 128-byte id (td_comm_unique_id), the caller broadcasts it with whatever
+ * it has (torch.distributed), every rank calls td_comm_init.  librccl.so is dlopen'ed on first use. */
+TD_API int td_comm_unique_id(void *id128);
+TD_API int td_comm_init(int world, int rank, const void *id128);
+TD_API int td_comm_destroy(void);
+TD_API int td_shard_rounds(td_shard *s, int rounds, uint64_t *keys);
 TD_API int td_shard_finish(td_shard *s, int world, const void *const *shard_ptrs, int rows_per_shard);
 TD_API int td_shard_owner(td_shard *s, int32_t *owner, int set);
 TD_API int td_shard_price(td_shard *s, int64_t *price /* n, device */, int set);

@@ -50,6 +50,10 @@ SIGNATURES = {
     "td_shard_keys_len": (ctypes.c_int, [ctypes.c_void_p]),
     "td_shard_bid": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "td_shard_apply": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "td_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "td_comm_init": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "td_comm_destroy": (ctypes.c_int, []),
+    "td_shard_rounds": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "td_shard_cc": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]),
     "td_shard_finish": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
     "td_shard_owner": (ctypes.c_int, [ctypes.c_void_p, c_i32p, ctypes.c_int]),

@@ -30,6 +30,7 @@
 // of them with 1-2 bidders — pure launch latency on a GPU.  eps = 0 rounds + SAP need <= 16
 // rounds and 10^2..10^4 in-kernel steps for the same instances and are exact by construction
 // (no (N+1) cost scaling needed).  See DESIGN.md.
+#include <dlfcn.h>
 #include <limits.h>
 #include <stdlib.h>
 
@@ -3425,6 +3426,114 @@ int td_shard_apply(td_shard *s, int round, uint64_t *keys)
     int rc;
     TD_DISPATCH(*s, sv_apply_t, *s, round, (unsigned long long *)keys);
     return rc;
+}
+
+// ---- the bidding rounds of a sharded solve as ONE call: bid -> RCCL MAX all-reduce -> apply, every
+// round enqueued on the library's stream with no host work in between.  RCCL is opened lazily with
+// dlopen (the copy the process has loaded already — torch's — else /opt/rocm's): a single-GPU user
+// of the library never loads it.
+struct Id128 {   // ncclUniqueId: 128 opaque bytes, passed to ncclCommInitRank BY VALUE
+    char b[128];
+};
+namespace {
+struct RcclApi {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    void *comm = nullptr;
+    int world = 0, rank = 0;
+};
+RcclApi g_rccl;
+constexpr int RCCL_UINT64 = 5;   // ncclUint64 (rccl.h ncclDataType_t)
+constexpr int RCCL_MAX = 2;      // ncclMax   (rccl.h ncclRedOp_t)
+
+int rccl_load()
+{
+    RcclApi &r = g_rccl;
+    if (r.h) return TD_OK;
+    const char *names[] = {"librccl.so", "librccl.so.1"};
+    for (const char *nm : names)
+        if (!r.h) r.h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+    for (const char *nm : names)
+        if (!r.h) r.h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    if (!r.h) return fail(TD_EINTERNAL, "librccl.so not found: %s", dlerror());
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy) {
+        r.h = nullptr;
+        return fail(TD_EINTERNAL, "librccl.so lacks the nccl entry points");
+    }
+    return TD_OK;
+}
+int rccl_fail(int e, const char *what)
+{
+    return fail(TD_EINTERNAL, "RCCL error %d (%s) in %s", e, g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?", what);
+}
+}  // namespace
+
+int td_comm_unique_id(void *id128)
+{
+    TD_REQUIRE_INIT();
+    if (!id128) return fail(TD_EINVAL, "null id");
+    int rc = rccl_load();
+    if (rc) return rc;
+    const int e = g_rccl.GetUniqueId(id128);
+    return e ? rccl_fail(e, "ncclGetUniqueId") : TD_OK;
+}
+
+int td_comm_init(int world, int rank, const void *id128)
+{
+    TD_REQUIRE_INIT();
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(TD_EINVAL, "bad communicator arguments");
+    int rc = rccl_load();
+    if (rc) return rc;
+    if (g_rccl.comm) {
+        (void)g_rccl.CommDestroy(g_rccl.comm);
+        g_rccl.comm = nullptr;
+    }
+    Id128 id;
+    memcpy(id.b, id128, sizeof(id.b));
+    const int e = g_rccl.CommInitRank(&g_rccl.comm, world, id, rank);
+    if (e) return rccl_fail(e, "ncclCommInitRank");
+    g_rccl.world = world;
+    g_rccl.rank = rank;
+    return TD_OK;
+}
+
+int td_comm_destroy(void)
+{
+    if (g_rccl.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g_rccl.comm);
+    g_rccl.comm = nullptr;
+    g_rccl.world = 0;
+    return TD_OK;
+}
+
+int td_shard_rounds(td_shard *s, int rounds, uint64_t *keys)
+{
+    TD_REQUIRE_INIT();
+    if (!s || !keys || rounds < 0 || rounds > 48) return fail(TD_EINVAL, "bad arguments to td_shard_rounds");
+    if (!is_device_ptr(keys)) return fail(TD_EINVAL, "bid keys must be device memory");
+    if (!g_rccl.comm) return fail(TD_ENOINIT, "td_comm_init has not been called");
+    Ctx &c = ctx();
+    int rc = TD_OK;
+    static const bool force_ar = getenv("TD_SHARD_FORCE_AR") != nullptr;   // measurement: all-reduce with one rank too
+    for (int r = 0; r < rounds; r++) {
+        TD_DISPATCH(*s, sv_bid_t, *s, r, (unsigned long long *)keys);
+        if (rc) return rc;
+        if (g_rccl.world > 1 || force_ar) {
+            const int e = g_rccl.AllReduce(keys, keys, (size_t)s->npad, RCCL_UINT64, RCCL_MAX, g_rccl.comm, c.stream);
+            if (e) return rccl_fail(e, "ncclAllReduce");
+        }
+        TD_DISPATCH(*s, sv_apply_t, *s, r, (unsigned long long *)keys);
+        if (rc) return rc;
+    }
+    return TD_OK;
 }
 
 int td_shard_cc(td_shard *s, void **ptr, uint64_t *bytes)

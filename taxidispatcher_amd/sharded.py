@@ -105,6 +105,34 @@ class HipShard:
         if not self.shared_stream:
             _ffi.check(self.lib.td_synchronize())
 
+    # -- all rounds in one C call, the collective issued by the library itself (td_shard_rounds)
+    _comm_key = None   # (world, rank) of the library's communicator in this process
+
+    def native_comm(self, dist):
+        """Builds (once per process) the library's own RCCL communicator: rank 0 makes the 128-byte
+        id, torch.distributed broadcasts it.  Returns False when RCCL cannot be used (gloo test runs,
+        TD_SHARD_NATIVE=0)."""
+        if os.environ.get("TD_SHARD_NATIVE", "1") == "0" or dist.get_backend() != "nccl":
+            return False
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if HipShard._comm_key == (world, rank):
+            return True
+        buf = (ctypes.c_ubyte * 128)()
+        if rank == 0:
+            _ffi.check(self.lib.td_comm_unique_id(buf))
+        t = self.torch.tensor(list(buf), dtype=self.torch.uint8, device=self.device)
+        if world > 1:
+            dist.broadcast(t, 0)
+        raw = bytes(t.cpu().numpy().tobytes())
+        idb = (ctypes.c_ubyte * 128).from_buffer_copy(raw)
+        self.torch.cuda.current_stream().synchronize()
+        _ffi.check(self.lib.td_comm_init(world, rank, idb))
+        HipShard._comm_key = (world, rank)
+        return True
+
+    def rounds_native(self, rounds, keys):
+        _ffi.check(self.lib.td_shard_rounds(self.h, int(rounds), keys.data_ptr()))
+
     # -- finisher support
     def export_handle(self):
         """64-byte hipIpc handle of the compressed shard (uint8 tensor on the device)."""
@@ -271,11 +299,15 @@ def _solve_sharded(shard, dist, rounds, want_dual, use_ipc):
     shard.begin(grange)
     # 2. Jacobi bidding rounds: ONE exchange step per round
     keys = shard.new_keys()
-    for r in range(rounds):
-        shard.bid(r, keys)
-        if world > 1:
-            all_reduce(dist, keys, MAX)
-        shard.apply(r, keys)
+    if hasattr(shard, "native_comm") and getattr(shard, "shared_stream", False) and shard.native_comm(dist):
+        # one C call: bid -> RCCL MAX all-reduce -> apply per round, all on the library's stream
+        shard.rounds_native(rounds, keys)
+    else:
+        for r in range(rounds):
+            shard.bid(r, keys)
+            if world > 1:
+                all_reduce(dist, keys, MAX)
+            shard.apply(r, keys)
     # 3. finisher on rank 0 over peer-mapped (or gathered) shards
     if use_ipc is None:
         use_ipc = os.environ.get("TD_SHARD_GATHER", "0") != "1"
