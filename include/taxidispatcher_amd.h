@@ -127,6 +127,24 @@ TD_API int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshold, i
 TD_API int td_pool2(int n, const int32_t *from, const int32_t *to, const int32_t *dist, int S,
                     int32_t *cust_a, int32_t *cust_b, int32_t *plan, int32_t *cost, int32_t *n_pairs);
 
+/* ---- f-4 pools of up to 4 passengers ---------------------------------------------------
+ * Replaces pool_n.c:101-207 (findPool / drop_customers / removeDuplicates; Pool.java:32-113 is the
+ * same enumeration) for ONE first-pick-up slice [first0, first1) — the unit findpool.c:138-141 hands
+ * to each of its 8 children (child t: first0 = t * (n/8 + 1), pool_n.c:243-246) — and the merge of
+ * the children's lists (findpool.c:73-98,166-172).
+ *   requests i = 0..n-1: from[i], to[i], max_wait[i] (pick-up path up to i may not be longer),
+ *   max_loss[i] (percent a pooled ride may exceed the direct one);  dist: S x S or NULL => |a-b|.
+ *   pools: max_pools records of 2k+1 ints (k pick-ups, k drop-offs, cost) in the reference's output
+ *   order (stable by cost, de-duplicated);  n_happy: happy plans before de-duplication;  max_happy:
+ *   capacity of the plan buffer (<= 0: 4 Mi plans; TD_ERANGE when exceeded — the reference's
+ *   pool[10000] simply overflows there).
+ */
+TD_API int td_pool_n(int k, int n, const int32_t *from, const int32_t *to, const int32_t *max_wait,
+                     const int32_t *max_loss, const int32_t *dist, int S, int first0, int first1,
+                     int64_t max_happy, int max_pools, int32_t *pools, int32_t *n_pools, int64_t *n_happy);
+TD_API int td_pool_merge(int k, int n_requests, int n_in, const int32_t *pools_in /* n_in * (2k+1) */,
+                         int sort_by_cost, int max_pools, int32_t *pools_out, int32_t *n_out);
+
 /* ---- a-7 objective evaluation  (greedy_opt.py:21-29 count_sum) ---------------------- */
 TD_API int td_count_sum(int n, const int32_t *cost, const int32_t *row_to_col, int64_t big_cost,
                  int64_t *sum, int32_t *n_real);

@@ -135,3 +135,21 @@ def solve_x(n, cost):
     x = np.zeros(n * n, np.uint8)
     x[np.arange(n) * n + r] = 1
     return x
+
+
+def pool_n(k, frm, to, wait, loss, dist=None, first0=0, first1=None, cap=200000):
+    """f-4 (pool_n.c): kept plans of one first-pick-up slice as an int32 array [m, 2k+1]
+    (pick-ups, drop-offs, cost) in the reference's output order, and the number of happy plans."""
+    frm, to, wait, loss = map(_i32, (frm, to, wait, loss))
+    n = int(frm.size)
+    first1 = n if first1 is None else first1
+    out = np.zeros((cap, 2 * k + 1), np.int32)
+    nh = ctypes.c_long(0)
+    d = None if dist is None else _i32(dist)
+    L = lib()
+    L.oracle_pool_n.restype = ctypes.c_long
+    m = L.oracle_pool_n(k, n, _p(frm), _p(to), _p(wait), _p(loss), _p(d), 0 if d is None else d.shape[0],
+                        int(first0), int(first1), ctypes.c_long(cap), _p(out), ctypes.byref(nh))
+    if m < 0:
+        raise OverflowError("more than %d happy plans" % cap)
+    return out[:m].copy(), int(nh.value)

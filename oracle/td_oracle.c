@@ -395,3 +395,122 @@ ORACLE_API void oracle_gen_uniform(int n, uint64_t seed, int32_t lo, int32_t hi,
             cost[(int64_t)i * n + j] = lo + (int32_t)(((h >> 32) * (uint64_t)span) >> 32);
         }
 }
+
+/* ------------------------------------------------------------------ */
+/* f-4: pools of up to 4 passengers (pool_n.c:101-207, Pool.java:32-113) */
+/* ------------------------------------------------------------------ */
+/* Own restatement, iterative.  A plan = an ordered pick-up sequence p[0..k) of distinct requests
+ * (first pick-up in [first0, first1): findpool.c:138-141 gives each of its 8 children such a
+ * slice, pool_n.c:243-246) and a drop-off order q = a permutation of 0..k-1 into p.
+ *   wait rule (pool_n.c:174-179): for every level l >= 1 the pick-up path p[0]->..->p[l] must not be
+ *     longer than WAIT of p[l]; a failing candidate is skipped, the enumeration goes on.
+ *   happiness (pool_n.c:105-122): passenger x = p[q[d]] rides  pick-up path from its own pick-up to
+ *     the last one + last pick-up -> first drop-off + drop-off path up to its own drop-off; that
+ *     must not exceed  direct(x) * (1 + LOSS(x) / 100.0)  (double arithmetic, `>` rejects).
+ *   cost of a plan (pool_n.c:129-137): whole pick-up path + last pick-up -> first drop + drop path.
+ * Plans are recorded in enumeration order (p lexicographic with the level-0 slice, then q
+ * lexicographic), sorted by cost — STABLY (glibc's qsort is a merge sort for arrays of this size,
+ * so equal costs keep the enumeration order; pool_n.c:198) — and a plan is dropped when it shares
+ * a request with an earlier kept plan (pool_n.c:200-215).  Output records: p[0..k), p[q[0..k)], cost.
+ * dist == NULL means |a-b| (pool_n.c:186-192).  Returns the number of kept plans, or -1 when more
+ * than `cap` happy plans exist (the reference's pool[MAX_ARR] would overflow there). */
+static inline int pool_dist(const int32_t *dist, int S, int a, int b)
+{
+    return dist ? dist[(int64_t)a * S + b] : (a > b ? a - b : b - a);
+}
+typedef struct { int32_t r[9]; int64_t seq; } pool_rec;
+static void pool_merge_sort(pool_rec *a, pool_rec *tmp, long n)
+{   /* stable merge sort by r[8] (cost) */
+    if (n < 2) return;
+    long h = n / 2;
+    pool_merge_sort(a, tmp, h);
+    pool_merge_sort(a + h, tmp, n - h);
+    long i = 0, j = h, k = 0;
+    while (i < h && j < n) tmp[k++] = (a[j].r[8] < a[i].r[8]) ? a[j++] : a[i++];
+    while (i < h) tmp[k++] = a[i++];
+    while (j < n) tmp[k++] = a[j++];
+    memcpy(a, tmp, sizeof(pool_rec) * (size_t)n);
+}
+ORACLE_API long oracle_pool_n(int k, int n, const int32_t *from, const int32_t *to, const int32_t *wait,
+                              const int32_t *loss, const int32_t *dist, int S, int first0, int first1,
+                              long cap, int32_t *out /* cap * (2k+1) */, long *n_happy)
+{
+    if (k < 1 || k > 4 || n < k) { if (n_happy) *n_happy = 0; return 0; }
+    pool_rec *rec = malloc(sizeof(pool_rec) * (size_t)(cap > 0 ? cap : 1));
+    long cnt = 0;
+    int p[4] = {0, 0, 0, 0}, lim[4];
+    int perm[24][4], np = 0;
+    {   /* permutations of 0..k-1 in lexicographic order (the recursion order of pool_n.c:140-153) */
+        int q[4];
+        for (q[0] = 0; q[0] < k; q[0]++)
+            for (q[1] = 0; q[1] < (k > 1 ? k : 1); q[1]++)
+                for (q[2] = 0; q[2] < (k > 2 ? k : 1); q[2]++)
+                    for (q[3] = 0; q[3] < (k > 3 ? k : 1); q[3]++) {
+                        int ok = 1;
+                        for (int a = 0; a < k && ok; a++)
+                            for (int b = a + 1; b < k; b++)
+                                if (q[a] == q[b]) { ok = 0; break; }
+                        if (!ok) continue;
+                        for (int a = 0; a < 4; a++) perm[np][a] = a < k ? q[a] : 0;
+                        np++;
+                    }
+    }
+    int overflow = 0;
+    /* odometer over the pick-up sequence; level 0 runs over the slice, deeper levels over all requests */
+    int level = 0;
+    p[0] = first0 - 1;
+    lim[0] = first1;
+    while (level >= 0) {
+        p[level]++;
+        if (p[level] >= (level == 0 ? lim[0] : n)) { level--; continue; }
+        int dup = 0;
+        for (int l = 0; l < level; l++) if (p[l] == p[level]) { dup = 1; break; }
+        if (dup) continue;
+        int path = 0;
+        for (int l = 0; l < level; l++) path += pool_dist(dist, S, from[p[l]], from[p[l + 1]]);
+        if (path > wait[p[level]]) continue;
+        if (level + 1 < k) { level++; p[level] = -1; continue; }
+        /* a complete pick-up sequence: all drop-off orders */
+        for (int qi = 0; qi < np; qi++) {
+            const int *q = perm[qi];
+            int happy = 1;
+            for (int d = 0; d < k && happy; d++) {
+                int c = 0;
+                for (int ph = q[d]; ph < k - 1; ph++) c += pool_dist(dist, S, from[p[ph]], from[p[ph + 1]]);
+                c += pool_dist(dist, S, from[p[k - 1]], to[p[q[0]]]);
+                for (int ph = 0; ph < d; ph++) c += pool_dist(dist, S, to[p[q[ph]]], to[p[q[ph + 1]]]);
+                const int x = p[q[d]];
+                if (c > pool_dist(dist, S, from[x], to[x]) * (1 + loss[x] / 100.0)) happy = 0;
+            }
+            if (!happy) continue;
+            if (cnt >= cap) { overflow = 1; cnt++; continue; }
+            pool_rec *r = &rec[cnt++];
+            memset(r->r, 0, sizeof(r->r));
+            for (int i = 0; i < k; i++) { r->r[i] = p[i]; r->r[i + k] = p[q[i]]; }
+            int c = 0;
+            for (int i = 0; i < k - 1; i++) c += pool_dist(dist, S, from[p[i]], from[p[i + 1]]);
+            c += pool_dist(dist, S, from[p[k - 1]], to[p[q[0]]]);
+            for (int i = 0; i < k - 1; i++) c += pool_dist(dist, S, to[p[q[i]]], to[p[q[i + 1]]]);
+            r->r[8] = c;
+        }
+    }
+    if (n_happy) *n_happy = cnt;
+    if (overflow) { free(rec); return -1; }
+    pool_rec *tmp = malloc(sizeof(pool_rec) * (size_t)(cnt > 0 ? cnt : 1));
+    pool_merge_sort(rec, tmp, cnt);
+    free(tmp);
+    char *used = calloc((size_t)n, 1);
+    long kept = 0;
+    for (long i = 0; i < cnt; i++) {
+        int clash = 0;
+        for (int a = 0; a < k; a++) if (used[rec[i].r[a]]) { clash = 1; break; }
+        if (clash) continue;
+        for (int a = 0; a < k; a++) used[rec[i].r[a]] = 1;
+        for (int a = 0; a < 2 * k; a++) out[kept * (2 * k + 1) + a] = rec[i].r[a];
+        out[kept * (2 * k + 1) + 2 * k] = rec[i].r[8];
+        kept++;
+    }
+    free(used);
+    free(rec);
+    return kept;
+}

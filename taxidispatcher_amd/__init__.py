@@ -6,9 +6,9 @@ kernels behind a C ABI (include/taxidispatcher_amd.h).  See DESIGN.md / INTEGRAT
 from . import _ffi
 from ._ffi import TdError, init, shutdown
 from .dispatch import (BIG_COST, LCM, LCM_heuristic, LCM_simulator, assign, calculate_cost, calculate_cost_by_id,
-                       combined, cost_build, count_sum, expand_x, filter_out, find_pool, last_stats, procedure_solve, solve,
-                       solve_cost)
+                       combined, cost_build, count_sum, expand_x, filter_out, find_pool, find_pool_n, last_stats, merge_pools,
+                       procedure_solve, solve, solve_cost)
 
 __all__ = ["TdError", "init", "shutdown", "BIG_COST", "LCM", "LCM_heuristic", "LCM_simulator", "assign",
            "calculate_cost", "calculate_cost_by_id", "combined", "cost_build", "count_sum", "expand_x", "filter_out", "find_pool",
-           "last_stats", "procedure_solve", "solve", "solve_cost"]
+           "find_pool_n", "merge_pools", "last_stats", "procedure_solve", "solve", "solve_cost"]

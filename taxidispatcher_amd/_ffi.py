@@ -38,6 +38,11 @@ SIGNATURES = {
                               ctypes.POINTER(ctypes.c_int32)]),
     "td_pool2": (ctypes.c_int, [ctypes.c_int, c_i32p, c_i32p, c_i32p, ctypes.c_int, c_i32p, c_i32p, c_i32p, c_i32p,
                                 ctypes.POINTER(ctypes.c_int32)]),
+    "td_pool_n": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, ctypes.c_int, ctypes.c_int,
+                                 ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_i32p, ctypes.POINTER(ctypes.c_int32),
+                                 ctypes.POINTER(ctypes.c_int64)]),
+    "td_pool_merge": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p, ctypes.c_int, ctypes.c_int, c_i32p,
+                                     ctypes.POINTER(ctypes.c_int32)]),
     "td_count_sum": (ctypes.c_int, [ctypes.c_int, c_i32p, c_i32p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64),
                                     ctypes.POINTER(ctypes.c_int32)]),
     "td_gen_uniform": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int,

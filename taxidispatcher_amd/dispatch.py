@@ -224,6 +224,47 @@ def find_pool(frm, to, distances=None):
     return [(int(a[i]), int(b[i]), int(plan[i]), int(cost[i])) for i in range(k.value)]
 
 
+def find_pool_n(k, demand, distances=None, child=None, children=8, max_happy=0):
+    """pool_n.c on the GPU.  demand: rows (id, from, to, max_wait, max_loss) like the reference's
+    demand file (pool_n.c:18,29-54; the id column is not used, requests are addressed by position).
+    child = t: only the first-pick-up slice findpool.c gives its child t of `children`
+    (pool_n.c:243-246); None: all requests as first pick-up.  Returns (int32 array [m, 2k+1] of
+    pick-ups, drop-offs, cost in the reference's output order, number of happy plans)."""
+    lib = _ffi.lib()
+    d = _ffi.as_i32(np.asarray(demand).reshape(len(demand), -1))
+    n = int(d.shape[0])
+    frm, to, wait, loss = (np.ascontiguousarray(d[:, c]) for c in (1, 2, 3, 4))
+    if child is None:
+        first0, first1 = 0, n
+    else:
+        step = n // children + 1
+        first0 = step * child
+        first1 = min(n, first0 + step)
+    dptr, S, keep = _dist_arg(distances)
+    cap = max(1, n // k + 1)
+    out = np.zeros((cap, 2 * k + 1), np.int32)
+    m = ctypes.c_int32(0)
+    nh = ctypes.c_int64(0)
+    _ffi.check(lib.td_pool_n(int(k), n, _ffi.addr(frm), _ffi.addr(to), _ffi.addr(wait), _ffi.addr(loss), dptr, S, int(first0),
+                             int(first1), int(max_happy), cap, _ffi.addr(out), ctypes.byref(m), ctypes.byref(nh)))
+    del keep
+    return out[:m.value].copy(), int(nh.value)
+
+
+def merge_pools(k, n_requests, lists):
+    """findpool.c:73-98,166-172: the children's lists (in child order) merged into one list of pools
+    that share no request; sorted by cost first for 4-passenger pools only, as the reference does."""
+    lib = _ffi.lib()
+    parts = [np.asarray(x, np.int32).reshape(-1, 2 * k + 1) for x in lists]
+    allp = np.ascontiguousarray(np.concatenate(parts, 0)) if parts else np.zeros((0, 2 * k + 1), np.int32)
+    cap = max(1, n_requests // k + 1)
+    out = np.zeros((cap, 2 * k + 1), np.int32)
+    m = ctypes.c_int32(0)
+    _ffi.check(lib.td_pool_merge(int(k), int(n_requests), int(allp.shape[0]), _ffi.addr(allp) if allp.size else None,
+                                 1 if k == 4 else 0, cap, _ffi.addr(out), ctypes.byref(m)))
+    return out[:m.value].copy()
+
+
 def count_sum(nn, cost, res, big_cost=BIG_COST):
     """greedy_opt.py:21-29 with positional lists: because cost[taxi][trip] IS
     dist[supply[taxi].to][demand[trip].from] for every real cell, the sum over x==1 cells with

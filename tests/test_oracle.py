@@ -250,3 +250,18 @@ print("asan ok")
                UBSAN_OPTIONS="halt_on_error=1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "asan ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_pool_n_oracle_matches_reference_outputs():
+    """f-4: the oracle's restatement of pool_n.c against the outputs of the reference binary itself
+    (tests/golden/pool_n, made by tests/golden/make_pool_fixtures.py from oracle/_ref/pool_n)."""
+    import pool_fixtures as pf
+    assert len(pf.cases()) >= 10
+    for name, k in pf.cases():
+        d, exp = pf.load(name, k)
+        n = len(d)
+        for child in range(8):
+            a, b = pf.child_slice(n, child)
+            out, nh = oracle.pool_n(k, d[:, 1], d[:, 2], d[:, 3], d[:, 4], None, a, b)
+            assert out.tolist() == exp[child], (name, k, child)
+            assert nh >= len(exp[child])
