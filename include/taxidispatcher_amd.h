@@ -116,6 +116,18 @@ TD_API int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshold, i
            int32_t stop_value, int stop_size, int64_t sum_below, int max_pairs,
            int32_t *rows, int32_t *cols, int32_t *n_pairs, int64_t *total, int32_t *last_min);
 
+/* Row-sharded LCM: rank r owns cost rows [row0, row0 + nrows).  Per pick every shard
+ * reports its smallest live cell {value, global row, column} (value = INT64_MAX: none), the caller
+ * takes the minimum in the reference's order (value, row, column) over all shards — one all-gather of
+ * 24 bytes per rank — applies td_lcm's stop rules and tells every shard the pick.  Pairs, total and
+ * last_min equal td_lcm's.  Host driver: taxidispatcher_amd/sharded.py lcm_sharded. */
+typedef struct td_lcm_shard td_lcm_shard;
+TD_API int td_lcm_shard_create(int n, int row0, int nrows, const int32_t *cost_rows, int stop_value_on,
+                               int32_t stop_value, td_lcm_shard **out);
+TD_API int td_lcm_shard_destroy(td_lcm_shard *s);
+TD_API int td_lcm_shard_local_min(td_lcm_shard *s, int64_t *out3);
+TD_API int td_lcm_shard_take(td_lcm_shard *s, int row, int col);
+
 /* ---- f-3 pool of two (the step right before the path in every tick) -------------------
  * Replaces findPool: Simulator.java:681-758 (and pool.c:64-131): every ordered pair (A, B) of
  * requests is a candidate with cost = min(plan1, plan2) (:693-717); plans are taken in STABLE

@@ -36,6 +36,11 @@ SIGNATURES = {
                               ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_i32p, c_i32p,
                               ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64),
                               ctypes.POINTER(ctypes.c_int32)]),
+    "td_lcm_shard_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p, ctypes.c_int, ctypes.c_int32,
+                                           ctypes.POINTER(ctypes.c_void_p)]),
+    "td_lcm_shard_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "td_lcm_shard_local_min": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
+    "td_lcm_shard_take": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "td_pool2": (ctypes.c_int, [ctypes.c_int, c_i32p, c_i32p, c_i32p, ctypes.c_int, c_i32p, c_i32p, c_i32p, c_i32p,
                                 ctypes.POINTER(ctypes.c_int32)]),
     "td_pool_n": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, ctypes.c_int, ctypes.c_int,

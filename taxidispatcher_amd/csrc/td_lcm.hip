@@ -689,6 +689,166 @@ __global__ void k_pool2_plans(int k, int n, const int32_t *__restrict__ from, co
 
 }  // namespace
 
+
+// =====================================================================================
+// Row-sharded LCM: rank r owns cost rows [row0, row0 + nrows) x all n columns.  Per
+// pick: every shard reports its smallest live cell in the reference's order (value, row, column),
+// the caller takes the lexicographic minimum over all shards (ONE small all-gather), every shard
+// masks the row / column and re-scans only its rows whose cached first minimum sat in the taken
+// column — the same bookkeeping as k_lcm_loop, so the pairs come out bit-identical to td_lcm.
+// The stop rules live in the host driver (taxidispatcher_amd/sharded.py lcm_sharded).
+// =====================================================================================
+struct td_lcm_shard {
+    int n = 0, row0 = 0, nrows = 0;
+    int64_t cand_limit = INT64_MAX;
+    const int32_t *d_cost = nullptr;
+    Buf stage, rowbest, colmask, out;
+};
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_lcmsh_init(int n, int nrows, const int32_t *__restrict__ cost, int64_t cand_limit,
+                                                    unsigned long long *__restrict__ rowbest)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int row = blockIdx.x * nw + w; row < nrows; row += gridDim.x * nw) {
+        const unsigned long long b = lcm_scan_row(cost + (int64_t)row * n, n, lane, nullptr, cand_limit);
+        if (lane == 0) rowbest[row] = b;
+    }
+}
+
+// smallest (value, row) among the local rows; out3 = {value, global row, column}, value = INT64_MAX when none
+__global__ __launch_bounds__(1024) void k_lcmsh_min(int nrows, int row0, const unsigned long long *__restrict__ rowbest,
+                                                    long long *__restrict__ out3)
+{
+    __shared__ unsigned long long s_red[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned long long best = LCM_INF;
+    for (int i = tid; i < nrows; i += 1024) {
+        const unsigned long long k = rowbest[i];
+        if (k != LCM_INF) {
+            const unsigned long long kk = (k & 0xFFFFFFFF00000000ull) | (uint32_t)i;
+            best = kk < best ? kk : best;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ob = __shfl_xor(best, o);
+        best = ob < best ? ob : best;
+    }
+    if (lane == 0) s_red[w] = best;
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < 16; k++) best = s_red[k] < best ? s_red[k] : best;
+        best = s_red[0] < best ? s_red[0] : best;
+        if (best == LCM_INF) {
+            out3[0] = LLONG_MAX;
+            out3[1] = -1;
+            out3[2] = -1;
+        } else {
+            const int r = (int)(uint32_t)best;
+            out3[0] = (long long)lcm_val(best);
+            out3[1] = (long long)(row0 + r);
+            out3[2] = (long long)(uint32_t)rowbest[r];
+        }
+    }
+}
+
+__global__ void k_lcmsh_mark(int row_local, int col, unsigned long long *rowbest, uint32_t *colmask)
+{
+    if (row_local >= 0) rowbest[row_local] = LCM_INF;
+    colmask[col >> 5] |= 1u << (col & 31);
+}
+
+__global__ __launch_bounds__(256) void k_lcmsh_rescan(int n, int nrows, int col, const int32_t *__restrict__ cost,
+                                                      int64_t cand_limit, unsigned long long *__restrict__ rowbest,
+                                                      const uint32_t *__restrict__ colmask)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int row = blockIdx.x * nw + w; row < nrows; row += gridDim.x * nw) {
+        const unsigned long long k = rowbest[row];
+        if (k == LCM_INF || (int)(uint32_t)k != col) continue;
+        const unsigned long long b = lcm_scan_row(cost + (int64_t)row * n, n, lane, colmask, cand_limit);
+        if (lane == 0) rowbest[row] = b;
+    }
+}
+
+}  // namespace
+
+extern "C" int td_lcm_shard_create(int n, int row0, int nrows, const int32_t *cost_rows, int stop_value_on,
+                                   int32_t stop_value, td_lcm_shard **out)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (!out) return fail(TD_EINVAL, "null out");
+    if (n < 1 || row0 < 0 || nrows < 0 || row0 + nrows > n) return fail(TD_EINVAL, "bad shard geometry n=%d row0=%d nrows=%d", n, row0, nrows);
+    if (nrows > 0 && !cost_rows) return fail(TD_EINVAL, "null cost rows");
+    td_lcm_shard *s = new td_lcm_shard();
+    s->n = n;
+    s->row0 = row0;
+    s->nrows = nrows;
+    s->cand_limit = stop_value_on ? (int64_t)stop_value : (int64_t)INT64_MAX;   // Simulator.java:529-537
+    int rc = TD_OK;
+    const void *d = nullptr;
+    if (nrows) rc = to_device(cost_rows, sizeof(int32_t) * (size_t)nrows * n, s->stage, &d);
+    if (!rc) rc = ensure(s->rowbest, sizeof(unsigned long long) * (size_t)std::max(nrows, 1));
+    if (!rc) rc = ensure(s->colmask, sizeof(uint32_t) * (size_t)((n + 31) / 32 + 1));
+    if (!rc) rc = ensure(s->out, 64);
+    if (rc) {
+        delete s;
+        return rc;
+    }
+    s->d_cost = (const int32_t *)d;
+    TD_HIP(hipMemsetAsync(s->colmask.p, 0, sizeof(uint32_t) * (size_t)((n + 31) / 32 + 1), c.stream));
+    if (nrows) {
+        ProfScope ps(TD_K_LCM);
+        k_lcmsh_init<<<std::max(1, std::min((nrows + 3) / 4, c.n_cu * 8)), 256, 0, c.stream>>>(n, nrows, s->d_cost, s->cand_limit,
+                                                                                             (unsigned long long *)s->rowbest.p);
+    }
+    TD_HIP(hipGetLastError());
+    *out = s;
+    return TD_OK;
+}
+
+extern "C" int td_lcm_shard_destroy(td_lcm_shard *s)
+{
+    TD_REQUIRE_INIT();
+    if (!s) return TD_OK;
+    (void)hipStreamSynchronize(ctx().stream);
+    Buf *bs[] = {&s->stage, &s->rowbest, &s->colmask, &s->out};
+    for (Buf *b : bs)
+        if (b->p) (void)hipFree(b->p);
+    delete s;
+    return TD_OK;
+}
+
+extern "C" int td_lcm_shard_local_min(td_lcm_shard *s, int64_t *out3)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (!s || !out3) return fail(TD_EINVAL, "null argument");
+    k_lcmsh_min<<<1, 1024, 0, c.stream>>>(s->nrows, s->row0, (const unsigned long long *)s->rowbest.p, (long long *)s->out.p);
+    TD_HIP(hipGetLastError());
+    TD_HIP(hipMemcpyAsync(c.pinned, s->out.p, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, c.stream));
+    TD_HIP(hipStreamSynchronize(c.stream));
+    memcpy(out3, c.pinned, 3 * sizeof(int64_t));
+    return TD_OK;
+}
+
+extern "C" int td_lcm_shard_take(td_lcm_shard *s, int row, int col)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (!s || col < 0 || col >= s->n || row < 0 || row >= s->n) return fail(TD_EINVAL, "bad pick (%d, %d)", row, col);
+    const int rl = (row >= s->row0 && row < s->row0 + s->nrows) ? row - s->row0 : -1;
+    k_lcmsh_mark<<<1, 1, 0, c.stream>>>(rl, col, (unsigned long long *)s->rowbest.p, (uint32_t *)s->colmask.p);
+    if (s->nrows)
+        k_lcmsh_rescan<<<std::max(1, std::min((s->nrows + 3) / 4, c.n_cu * 8)), 256, 0, c.stream>>>(
+            s->n, s->nrows, col, s->d_cost, s->cand_limit, (unsigned long long *)s->rowbest.p, (const uint32_t *)s->colmask.p);
+    TD_HIP(hipGetLastError());
+    return TD_OK;
+}
+
 extern "C" int td_pool2(int n, const int32_t *from, const int32_t *to, const int32_t *dist, int S, int32_t *cust_a,
                         int32_t *cust_b, int32_t *plan, int32_t *cost, int32_t *n_pairs)
 {

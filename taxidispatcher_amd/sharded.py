@@ -374,3 +374,102 @@ def assign_sharded(cost_rows, n, want_dual=False, rounds=DEFAULT_ROUNDS, dist=No
         return solve_sharded(sh, dist, rounds, want_dual)
     finally:
         sh.close()
+
+
+def pool_fanout(k, demand, dist, children=8, finder=None, merger=None):
+    """findpool.c's 8-way fan-out mapped to GPUs: child t (a first-pick-up slice, pool_n.c:243-246)
+    runs on rank t % world, the lists travel to rank 0 (all_gather_object: a few KiB), rank 0 merges
+    (findpool.c:73-98,166-172) and broadcasts the result.  No data-path collective besides that.
+    `finder(k, demand, child)` -> records, `merger(k, n, lists)` -> records default to the GPU
+    entry points; the gloo test injects host models."""
+    if finder is None or merger is None:
+        from . import dispatch
+        finder = finder or (lambda kk, dd, child: dispatch.find_pool_n(kk, dd, child=child, children=children)[0])
+        merger = merger or dispatch.merge_pools
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = {t: np.asarray(finder(k, demand, t)).reshape(-1, 2 * k + 1).tolist() for t in range(children) if t % world == rank}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    lists = {}
+    for g in gathered:
+        lists.update(g)
+    out = [None]
+    if rank == 0:
+        out[0] = np.asarray(merger(k, len(demand), [lists[t] for t in range(children)])).reshape(-1, 2 * k + 1).tolist()
+    dist.broadcast_object_list(out, src=0)
+    return np.asarray(out[0], np.int32).reshape(-1, 2 * k + 1)
+
+
+# ----------------------------------------------------------------------------------------
+# row-sharded LCM (SURVEY 8e)
+# ----------------------------------------------------------------------------------------
+INT64_MAX = 2**63 - 1
+
+
+class HipLcmShard:
+    """One rank's rows for the sharded lowest-cost method (td_lcm_shard_*)."""
+
+    def __init__(self, n, row0, nrows, cost_rows, stop_value_on=0, stop_value=0):
+        self.lib = _ffi.lib()
+        self.n, self.row0, self.nrows = n, row0, nrows
+        self._cost = cost_rows
+        h = ctypes.c_void_p()
+        _ffi.check(self.lib.td_lcm_shard_create(n, row0, nrows, _ffi.addr(cost_rows) if nrows else None, int(stop_value_on),
+                                                int(stop_value), ctypes.byref(h)))
+        self.h = h
+
+    def local_min(self):
+        out = (ctypes.c_int64 * 3)()
+        _ffi.check(self.lib.td_lcm_shard_local_min(self.h, out))
+        return (int(out[0]), int(out[1]), int(out[2]))
+
+    def take(self, row, col):
+        _ffi.check(self.lib.td_lcm_shard_take(self.h, int(row), int(col)))
+
+    def close(self):
+        if self.h:
+            self.lib.td_lcm_shard_destroy(self.h)
+            self.h = None
+
+
+def lcm_sharded(shards, dist, n, mask, threshold=-1, stop_value_on=0, stop_value=0, stop_size=-1, sum_below=INT64_MAX,
+                max_pairs=None):
+    """The lowest-cost method over row shards, stop rules exactly as td_lcm / k_lcm_loop
+    (greedy_opt.py:61-82, heuristic.py:24-33, Simulator.java:523-549).  `shards`: the shard(s) this
+    rank owns (objects with local_min() -> (value, global row, col) and take(row, col)); `dist`:
+    torch.distributed or None for a single process.  One all-gather of 24 bytes per rank and pick.
+    Returns (total, rows, cols, last_min), identical on every rank."""
+    import torch
+    world = dist.get_world_size() if dist is not None else 1
+    pairs_r, pairs_c = [], []
+    total, size = 0, n
+    last_min = stop_value
+    iters = n if max_pairs is None else min(n, max_pairs)
+    for _ in range(iters):
+        best = min((s.local_min() for s in shards), default=(INT64_MAX, -1, -1))
+        if world > 1:
+            t = torch.tensor(best, dtype=torch.int64)
+            out = [torch.empty(3, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(out, t)
+            best = min(tuple(int(x) for x in o.tolist()) for o in out)
+        v, r, c = best
+        if v == INT64_MAX:                      # nothing left to look at
+            last_min = stop_value if stop_value_on else mask
+            break
+        last_min = v
+        if threshold >= 0 and v > threshold:    # greedy_opt.py:68-69
+            break
+        if stop_value_on and v >= stop_value:   # Simulator.java:538
+            break
+        if v >= mask:                           # only masked-valued cells remain
+            break
+        pairs_r.append(r)
+        pairs_c.append(c)
+        if v < sum_below:
+            total += v
+        size -= 1
+        for s in shards:
+            s.take(r, c)
+        if stop_size >= 0 and size == stop_size:   # Simulator.java:544-545
+            break
+    return total, pairs_r, pairs_c, last_min

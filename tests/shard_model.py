@@ -150,3 +150,30 @@ class ModelShard:
 
     def close(self):
         pass
+
+
+class ModelLcmShard:
+    """numpy model of td_lcm_shard_* (one rank's rows of the sharded lowest-cost method)."""
+
+    def __init__(self, n, row0, nrows, cost_rows, stop_value_on=0, stop_value=0):
+        self.n, self.row0, self.nrows = n, row0, nrows
+        self.c = np.asarray(cost_rows, np.int64).reshape(nrows, n).copy()
+        self.limit = stop_value if stop_value_on else None
+        self.row_live = np.ones(nrows, bool)
+        self.col_live = np.ones(n, bool)
+
+    def local_min(self):
+        best = (2**63 - 1, -1, -1)
+        for i in np.nonzero(self.row_live)[0]:
+            row = np.where(self.col_live, self.c[i], 2**62)
+            if self.limit is not None:
+                row = np.where(row < self.limit, row, 2**62)
+            j = int(np.argmin(row))                     # first minimum: smallest column
+            if row[j] < 2**62:
+                best = min(best, (int(row[j]), self.row0 + int(i), j))
+        return best
+
+    def take(self, row, col):
+        if self.row0 <= row < self.row0 + self.nrows:
+            self.row_live[row - self.row0] = False
+        self.col_live[col] = False

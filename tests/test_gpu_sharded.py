@@ -108,3 +108,38 @@ def test_single_rank_shard_api_matches_td_assign(td):
     assert total == t_ref == dual == oracle.assign(cost)[0]
     assert np.array_equal(r2c, r_ref)
     dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_lcm_sharded_bit_identical_to_td_lcm(td):
+    """SURVEY 8e sharded LCM on the GPU: 1, 3 and 8 row shards (td_lcm_shard_*) driven in one
+    process give td_lcm's pair list, total and last_min for the reference variants."""
+    import numpy as np
+    from taxidispatcher_amd import dispatch, sharded
+    rng = np.random.default_rng(21)
+    BIG = 250000
+    # Simulator.java tick shape: 1300 cabs x 900 requests, stop at 600 left / on big_cost
+    a, b = rng.integers(0, 50, 1300), rng.integers(0, 50, 900)
+    n, cost = td.cost_build(a, b, None, fill=BIG, threshold=10)
+    variants = [
+        (cost, dict(mask=BIG, stop_value_on=1, stop_value=BIG, stop_size=600, sum_below=BIG)),    # Simulator.java:523-549
+        (cost, dict(mask=BIG, threshold=10, sum_below=BIG)),                                      # greedy_opt.py:61-82
+        (rng.integers(1, 40, (100, 100)).astype(np.int32), dict(mask=100)),                       # heuristic.py:24-33
+        (cost[:333, :333].copy(), dict(mask=BIG, stop_value_on=1, stop_value=BIG, stop_size=0, sum_below=BIG)),
+    ]
+    for c, kw in variants:
+        n = c.shape[0]
+        ref = dispatch._lcm(n, c, kw["mask"], kw.get("threshold", -1), kw.get("stop_value_on", 0), kw.get("stop_value", 0),
+                            kw.get("stop_size", -1), kw.get("sum_below", 2**62))
+        for world in (1, 3, 8):
+            shards = []
+            try:
+                for r in range(world):
+                    row0, nrows, _ = sharded.shard_bounds(n, world, r)
+                    shards.append(sharded.HipLcmShard(n, row0, nrows, np.ascontiguousarray(c[row0:row0 + nrows]),
+                                                      kw.get("stop_value_on", 0), kw.get("stop_value", 0)))
+                tot, rows, cols, lm = sharded.lcm_sharded(shards, None, n, **kw)
+            finally:
+                for s in shards:
+                    s.close()
+            assert tot == ref[0] and rows == ref[1].tolist() and cols == ref[2].tolist() and lm == ref[3], (n, world)

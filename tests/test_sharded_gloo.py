@@ -102,3 +102,114 @@ def test_three_ranks_uneven_shards():
     r3, t3, d3 = _run(3, "g1", n, 9)
     assert t3 == oracle.assign(cost)[0] == d3
     assert sorted(r3.tolist()) == list(range(n))
+
+
+def _pool_worker(rank, world, port, name, k, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pool_fixtures as pf
+    from oracle import oracle
+    from taxidispatcher_amd import sharded
+    d, _ = pf.load(name, k)
+    n = len(d)
+
+    def finder(kk, dd, child):      # host model of td_pool_n for one child slice
+        a, b = pf.child_slice(n, child)
+        return oracle.pool_n(kk, dd[:, 1], dd[:, 2], dd[:, 3], dd[:, 4], None, a, b)[0]
+
+    out = sharded.pool_fanout(k, d, dist, finder=finder, merger=lambda kk, nn, lists: pf.merge_restatement(kk, lists))
+    q.put((rank, out.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pool_fanout_over_ranks(world):
+    """f-4 fan-out (findpool.c's 8 children) over `world` ranks: every rank ends with the merge of
+    the reference's own child outputs."""
+    import pool_fixtures as pf
+    name, k = "b120", 4
+    _, exp = pf.load(name, k)
+    ref = pf.merge_restatement(k, [exp[c] for c in range(8)])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pool_worker, args=(r, world, port, name, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, got in outs:
+        assert got == ref
+
+
+def _lcm_worker(rank, world, port, n, seed, variant, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from shard_model import ModelLcmShard
+    from taxidispatcher_amd import sharded
+    cost = _lcm_instance(n, seed)
+    row0, nrows, _ = sharded.shard_bounds(n, world, rank)
+    kw = _LCM_VARIANTS[variant]
+    sh = ModelLcmShard(n, row0, nrows, cost[row0:row0 + nrows], kw.get("stop_value_on", 0), kw.get("stop_value", 0))
+    out = sharded.lcm_sharded([sh], dist, n, **kw)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _lcm_instance(n, seed):
+    rng = np.random.default_rng(seed)
+    a, b = rng.integers(0, 50, n), rng.integers(0, 50, max(1, int(0.7 * n)))
+    c = np.full((n, n), 250000, np.int32)
+    d = np.abs(a[:, None] - b[None, :])
+    c[:, :b.size] = np.where(d < 10, d, 250000)
+    return c
+
+
+_LCM_VARIANTS = {
+    "greedy_opt": dict(mask=250000, threshold=10, sum_below=250000),                                   # greedy_opt.py:61-82
+    "simulator": dict(mask=250000, stop_value_on=1, stop_value=250000, stop_size=20, sum_below=250000),  # Simulator.java:523-549
+    "heuristic": dict(mask=100),                                                                        # heuristic.py:24-33
+}
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("variant", ["greedy_opt", "simulator", "heuristic"])
+def test_lcm_sharded_equals_oracle(world, variant):
+    """SURVEY 8e sharded LCM: the collective driver (product code) over numpy shard models gives the
+    oracle's pair list, total and last_min."""
+    from oracle import oracle
+    n, seed = 57, 11
+    cost = _lcm_instance(n, seed)
+    if variant == "heuristic":
+        cost = np.random.default_rng(seed).integers(1, 40, (n, n)).astype(np.int32)
+        globals()["_lcm_instance"] = lambda nn, ss: np.random.default_rng(ss).integers(1, 40, (nn, nn)).astype(np.int32)
+    kw = _LCM_VARIANTS[variant]
+    tot_o, rows_o, cols_o, lm_o = oracle.lcm(cost, mask=kw["mask"], threshold=kw.get("threshold", -1),
+                                             stop_value_on=kw.get("stop_value_on", 0), stop_value=kw.get("stop_value", 0),
+                                             stop_size=kw.get("stop_size", -1), sum_below=kw.get("sum_below", 2**62),
+                                             java_scan=kw.get("stop_value_on", 0))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lcm_worker_v, args=(r, world, port, n, seed, variant, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, (tot, rows, cols, lm) in outs:
+        assert tot == tot_o and rows == rows_o.tolist() and cols == cols_o.tolist()
+        assert lm == lm_o
+
+
+def _lcm_worker_v(rank, world, port, n, seed, variant, q):
+    if variant == "heuristic":
+        globals()["_lcm_instance"] = lambda nn, ss: np.random.default_rng(ss).integers(1, 40, (nn, nn)).astype(np.int32)
+    _lcm_worker(rank, world, port, n, seed, variant, q)
