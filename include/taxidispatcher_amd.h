@@ -93,6 +93,12 @@ TD_API int td_cost_build_rows(const int32_t *cab_to, const int32_t *cab_id, int 
  *   total       optimal objective (exact integer, equals GLPK's optimum)
  *   dual_bound  may be NULL; else an LP-duality lower bound computed on the device from the
  *               final prices: dual_bound == total certifies optimality.
+ * One solver per process: td_assign works in ONE grow-only device workspace owned by the library
+ * (no hipMalloc after the first call of a size), like the reference, which solves one model at a
+ * time per process (Simulator.java:195-205 waits for its child).  Calls are serialised by the
+ * caller; consecutive calls of any sizes are independent (tests/test_gpu_parity.py::
+ * test_workspace_reuse_across_sizes).  Row shards (td_shard_*) each own a workspace, so several
+ * shards may live in one process.
  */
 TD_API int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_t *total,
               int64_t *dual_bound);

@@ -564,3 +564,19 @@ def test_n65536_full_size_single_gpu(td):
     assert int(cost[torch.arange(n, device="cuda"), idx].max().item()) == 10
     del cost
     torch.cuda.empty_cache()
+
+
+def test_workspace_reuse_across_sizes(td):
+    """The single-solver rule of td_assign (header): one grow-only workspace, consecutive calls of
+    any sizes and widths are independent of each other."""
+    rng = np.random.default_rng(77)
+    seq = [("g1", 1500), ("g3", 700), ("g2", 90), ("g1", 33), ("wide", 400), ("g1", 1500), ("g4", 100), ("g3", 1301)]
+    first = {}
+    for kind, n in seq:
+        c = make_instance(kind, n, np.random.default_rng(n * 7 + len(kind)))
+        r2c, total = check_assignment(td, c)
+        key = (kind, n)
+        if key in first:     # the same instance again, after other sizes used the workspace: same answer, bit for bit
+            assert first[key][1] == total and np.array_equal(first[key][0], r2c)
+        first[key] = (r2c, total)
+    del rng
