@@ -148,8 +148,14 @@ def addr(a):
     if isinstance(a, int):
         return a
     if isinstance(a, np.ndarray):
+        if not a.flags["C_CONTIGUOUS"]:
+            raise TdError("array handed to the C ABI must be C-contiguous")
         return a.ctypes.data
     if hasattr(a, "data_ptr"):
+        # the ABI reads plain row-major memory: a strided view (or a tensor of another width where
+        # int32 is expected) would be read as garbage, not refused, by the kernels
+        if hasattr(a, "is_contiguous") and not a.is_contiguous():
+            raise TdError("tensor handed to the C ABI must be contiguous")
         # The library works on its own HIP stream (td_set_stream changes that). A CUDA tensor may
         # still be being written by kernels queued on torch's current stream, and torch may hand
         # its memory to the next tensor the moment it is released: fence torch's stream before

@@ -40,6 +40,12 @@ def _records(rows):
     return np.ascontiguousarray(a[:, 0]), np.ascontiguousarray(a[:, 1]), np.ascontiguousarray(a[:, 2])
 
 
+def _require_i32(t, what):
+    """device tensors go to the kernels as they are: they must be int32 (numpy inputs are converted)"""
+    if hasattr(t, "data_ptr") and str(getattr(t, "dtype", "")) != "torch.int32":
+        raise _ffi.TdError("%s: a torch tensor handed to the library must be int32, got %s" % (what, t.dtype))
+
+
 def _dist_arg(distances):
     """distances: None (=> |a-b|), an S x S array-like, or a (device_ptr, S) tuple."""
     if distances is None:
@@ -47,7 +53,10 @@ def _dist_arg(distances):
     if isinstance(distances, tuple):
         return distances[0], int(distances[1]), None
     if hasattr(distances, "data_ptr") and getattr(distances, "is_cuda", False):
-        return distances.data_ptr(), int(distances.shape[0]), distances
+        _require_i32(distances, "distances")
+        if distances.dim() != 2 or distances.shape[0] != distances.shape[1]:
+            raise _ffi.TdError("distances must be a square S x S table")
+        return _ffi.addr(distances), int(distances.shape[0]), distances   # addr() fences torch's stream
     d = _ffi.as_i32(distances)
     if d.ndim != 2 or d.shape[0] != d.shape[1]:
         raise _ffi.TdError("distances must be a square S x S table")
@@ -85,6 +94,8 @@ def assign(cost, n=None, want_dual=False):
     lib = _ffi.lib()
     if isinstance(cost, np.ndarray) or not hasattr(cost, "data_ptr"):
         cost = _ffi.as_i32(cost)
+    else:
+        _require_i32(cost, "cost")
     if n is None:
         n = int(cost.shape[0])
     r2c = np.empty(n, np.int32)

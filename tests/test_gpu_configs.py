@@ -261,3 +261,19 @@ def test_sparse_core_forest_path(td):
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "'forest'" in r.stdout and "FAILURES: 0" in r.stdout
+
+
+def test_wrappers_refuse_wrong_dtype_or_strided_tensors(td):
+    """torch CUDA tensors go to the kernels as they are, so the wrappers check them."""
+    import torch
+    from taxidispatcher_amd import _ffi
+    c64 = torch.zeros((8, 8), dtype=torch.int64, device="cuda")
+    with pytest.raises(_ffi.TdError):
+        td.assign(c64)
+    c = torch.randint(0, 50, (16, 16), dtype=torch.int32, device="cuda")
+    with pytest.raises(_ffi.TdError):
+        td.assign(c.t())                       # a transposed view is not contiguous
+    r2c, total = td.assign(c.t().contiguous())
+    assert total == oracle.assign(c.t().cpu().numpy())[0]
+    with pytest.raises(_ffi.TdError):
+        td.find_pool(np.array([1, 2, 3]), np.array([2, 3, 4]), torch.zeros((5, 5), dtype=torch.float32, device="cuda"))
