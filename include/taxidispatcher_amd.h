@@ -238,7 +238,8 @@ TD_API int td_profile_get(int kernel, double *total_ms, int64_t *launches);
 TD_API int td_profile_reset(void);
 /* counters of the last td_assign: [0]=bid rounds, [1]=rounds of the eps > 0 price warm start,
  * [2]=free rows left to the serial finisher, [3]=its dijkstra steps, [4]=cost storage bytes per cell,
- * [5]=augmentations committed by the parallel finisher, [7]=1 when the transposed formulation was solved
+ * [5]=augmentations committed by the parallel finisher, [6]=1 when 4-byte cells were solved with 32-bit prices and labels,
+ * [7]=1 when the transposed formulation was solved
  * (many constant columns, see DESIGN.md "rectangular models") */
 TD_API int td_last_stats(int64_t *out, int n);
 

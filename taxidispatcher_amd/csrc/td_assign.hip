@@ -34,6 +34,8 @@
 #include <limits.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "td_common.h"
 
 using namespace td;
@@ -68,6 +70,40 @@ struct Tr<uint32_t> {
     static constexpr int64_t LIMIT = 0xFFFFFFFEll;
     static constexpr int64_t BIG = 1ll << 56;
     static constexpr int64_t KMAX = INT64_MAX;
+};
+
+// 32-bit cells with 32-BIT prices, keys and labels ("narrow price" mode, bpc code 5): rows whose
+// range needs 4-byte cells but is small (<= NP_RANGE, e.g. the |a-b| geometry: range 163 839 at
+// N = 16 384).  Same storage as uint32_t rows; every price / bid key / Dijkstra label is an int32, which
+// halves the registers and the ALU work of the finishers (k_sap<u32,4,SPEC> spilled 98 VGPRs with
+// 64-bit labels; k_sapx's relax is issue-bound on 64-bit compares).  Safety: prices only ever grow,
+// and every kernel that raises a price checks the new value against NP_PLIMIT — a breach sets
+// CTL_FLAG bit 3, every later kernel exits, the host redoes the solve with 64-bit prices.  With
+// prices < 2^27 and cells < 2^22 no label (price + cell + a path of raises) can wrap an int32.
+struct u32n {
+    uint32_t v;
+    u32n() = default;
+    __host__ __device__ constexpr u32n(uint32_t x) : v(x) {}
+    __host__ __device__ constexpr operator uint32_t() const { return v; }
+};
+constexpr int64_t NP_RANGE = (1 << 22) - 2;
+constexpr int32_t NP_PLIMIT = 1 << 27;
+template <>
+struct Tr<u32n> {
+    using PT = int32_t;
+    static constexpr int E = 4;
+    static constexpr uint32_t SENT = 0xFFFFFFFFu;
+    static constexpr int64_t LIMIT = NP_RANGE;
+    static constexpr int32_t BIG = 1 << 28;
+    static constexpr int32_t KMAX = INT32_MAX;
+};
+template <typename CT>
+struct IsNP {
+    static constexpr bool value = false;
+};
+template <>
+struct IsNP<u32n> {
+    static constexpr bool value = true;
 };
 
 // control block (int32 words) in device memory
@@ -129,6 +165,8 @@ int g_core_warm = 0;        // TD_CORE_WARM     eps phases before the core is ex
 int g_core_iters = 8;       // TD_CORE_ITERS    pricing passes before the dense finisher takes over
 int g_core_stucks = 2;      // TD_CORE_STUCKS   stuck searches that get cells appended and resume; then the dense finisher takes the rest
 int g_core_stuck_free = 64; // TD_CORE_STUCK_FREE ... only when at most this many rows are still free
+int g_narrow_price = 1;     // TD_NARROW_PRICE  4-byte cells with a row range <= 2^22: 32-bit prices and labels first (redone in 64 bits if a price reaches 2^27)
+long long g_np_plimit = NP_PLIMIT;   // TD_NP_PLIMIT  (tests) lower price limit of the narrow-price mode in k_assign / k_pcommit
 int g_solver_eps = 0;       // TD_SOLVER=eps    literal eps-scaling auction (comparison mode)
 int g_eps_theta = 8;        // TD_EPS_THETA
 long long g_eps0_mult = 4;  // TD_EPS0_MULT     eps0 = (n+1) * mult ; 0 = start at eps = 1
@@ -168,6 +206,8 @@ void read_tunables()
     if (const char *e = getenv("TD_CORE_ITERS")) g_core_iters = std::max(1, atoi(e));
     if (const char *e = getenv("TD_CORE_STUCKS")) g_core_stucks = std::max(0, atoi(e));
     if (const char *e = getenv("TD_CORE_STUCK_FREE")) g_core_stuck_free = std::max(0, atoi(e));
+    if (const char *e = getenv("TD_NARROW_PRICE")) g_narrow_price = atoi(e) != 0;
+    if (const char *e = getenv("TD_NP_PLIMIT")) g_np_plimit = std::max(1ll, std::min((long long)NP_PLIMIT, atoll(e)));
     if (const char *e = getenv("TD_SOLVER")) g_solver_eps = (strcmp(e, "eps") == 0);
     if (const char *e = getenv("TD_EPS0_MULT")) g_eps0_mult = std::max(0ll, atoll(e));
     if (const char *e = getenv("TD_EPS_THETA")) g_eps_theta = std::max(2, atoi(e));
@@ -205,6 +245,14 @@ __device__ __forceinline__ void unpack<uint16_t>(const uint4 &v, uint32_t *o)
 }
 template <>
 __device__ __forceinline__ void unpack<uint32_t>(const uint4 &v, uint32_t *o)
+{
+    o[0] = v.x;
+    o[1] = v.y;
+    o[2] = v.z;
+    o[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void unpack<u32n>(const uint4 &v, uint32_t *o)
 {
     o[0] = v.x;
     o[1] = v.y;
@@ -677,7 +725,7 @@ __global__ __launch_bounds__(256) void k_bid_row(int n, int nrows, int row0, int
 template <typename PT>
 __global__ __launch_bounds__(256) void k_assign(int n, int nrows, int row0, unsigned long long *__restrict__ bid,
                                                 PT *__restrict__ pk, int *__restrict__ owner, int *__restrict__ r2c,
-                                                int *__restrict__ ctl, int round)
+                                                int *__restrict__ ctl, int round, long long plimit = 0 /* narrow-price mode: flag prices at or above */)
 {
     if (ctl[CTL_FLAG]) return;
     if (round > 0 && round < 60 && ctl[CTL_PROG + round - 1] == 0) return;   // round >= 60: eps mode, always apply
@@ -688,6 +736,7 @@ __global__ __launch_bounds__(256) void k_assign(int n, int nrows, int row0, unsi
         if (k) {
             const int row = (int)(k & ((1ull << ROW_BITS) - 1)) - 1;
             const PT newp = (PT)(k >> ROW_BITS);
+            if (plimit && (long long)(k >> ROW_BITS) >= plimit) atomicOr(&ctl[CTL_FLAG], 8);
             const int old = owner[j];
             const PT oldp = pk[j] >> 1;
             // r2c holds this shard's rows only; owner/price are replicated on every shard
@@ -1388,6 +1437,9 @@ __global__ __launch_bounds__(TB) void k_sap(int n, int nchunks, const ShardTab t
                         preg[q * E + e] += mind - d[q * E + e];
                     else
                         P[j] = P[j] + (mind - d[q * E + e]);
+                    if constexpr (IsNP<CT>::value) {   // narrow-price mode: a price at the limit ends the attempt
+                        if ((PREG ? preg[q * E + e] : P[j]) >= (PT)NP_PLIMIT) atomicOr(&ctl[CTL_FLAG], 8);
+                    }
                 }
             }
         }
@@ -1474,10 +1526,12 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
                                              const int *__restrict__ list, int *__restrict__ ctl, SxShared *sh)
 {
     using PT = typename Tr<CT>::PT;
-    typedef long long LT;
+    // labels in the width of the prices: 32-bit for u8 rows and the narrow-price mode (prices < 2^28
+    // there), which halves the ALU work of the relax loop
+    typedef typename std::conditional<sizeof(PT) == 4, int, long long>::type LT;
     constexpr int E = Tr<CT>::E;
     constexpr int NW = TX / 64;
-    constexpr LT LMAX = (LT)1 << 62;
+    constexpr LT LMAX = sizeof(LT) == 4 ? (LT)(1 << 30) : (LT)((long long)1 << 62);
     __shared__ LT s_k[NW], s_p[NW], s_f[NW];
     __shared__ int s_j[NW], s_o[NW], s_fj[NW], s_wcnt[NW];
     __shared__ SxSlot s_slot[SX_KMAX];
@@ -1813,7 +1867,12 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
         // dual update on columns whose (exact) label is below the end distance
 #pragma unroll
         for (int e = 0; e < E; e++)
-            if (((scanned >> e) & 1u) && ((valid >> e) & 1u) && d[e] < mind) preg[e] += mind - d[e];
+            if (((scanned >> e) & 1u) && ((valid >> e) & 1u) && d[e] < mind) {
+                preg[e] += mind - d[e];
+                if constexpr (IsNP<CT>::value) {
+                    if (preg[e] >= (LT)NP_PLIMIT) atomicOr(&ctl[CTL_FLAG], 8);
+                }
+            }
         if (wg == 0 && tid == 0) {   // flip the path (pred / owner are global; the barrier made them visible)
             int j = endcol;
             for (int hop = 0; hop <= n; hop++) {
@@ -2177,7 +2236,8 @@ template <typename PT>
 __global__ __launch_bounds__(1024) void k_pcommit(int n, PT *__restrict__ pk, int *__restrict__ owner, int *__restrict__ r2c,
                                                   int *__restrict__ list, int *__restrict__ ctl,
                                                   unsigned long long *__restrict__ raise,  // n words, all zero on entry/exit
-                                                  const PsRec<PT> *__restrict__ recs, int first, int ngrid = PS_G)
+                                                  const PsRec<PT> *__restrict__ recs, int first, int ngrid = PS_G,
+                                                  long long plimit = 0 /* narrow-price mode: flag prices at or above */)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     int *touch = reinterpret_cast<int *>(smem);  // n ints
@@ -2245,7 +2305,10 @@ __global__ __launch_bounds__(1024) void k_pcommit(int n, PT *__restrict__ pk, in
         for (int k = lane; k < rc->nS; k += 64) {
             const int col = rc->S_col[k];
             const unsigned long long rv = atomicExch(&raise[col], 0ull);
-            if (rv) pk[col] = pk[col] + (PT)((PT)rv << 1);
+            if (rv) {
+                if (plimit && (long long)(pk[col] >> 1) + (long long)rv >= plimit) atomicOr(&ctl[CTL_FLAG], 8);
+                pk[col] = pk[col] + (PT)((PT)rv << 1);
+            }
         }
         if (lane == 0) pk[rc->endcol] = pk[rc->endcol] | (PT)1;  // the end column has an owner now
     }
@@ -2475,7 +2538,7 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
         if (!*fits) c.stats[6] = (int64_t)(((const unsigned long long *)((int *)c.pinned + CTL_RANGE))[0]);
     }
     if (*fits) {
-        sv.bpc = (int)sizeof(CT);
+        sv.bpc = IsNP<CT>::value ? 5 : (int)sizeof(CT);   // 5: 4-byte cells, 32-bit prices
         sv.nchunks = nchunks;
         sv.npad = nchunks * E;
     }
@@ -2488,6 +2551,7 @@ int sv_compress(Solver &sv, int bpc, bool *fits, bool speculate = false)
         case 1: return sv_compress_t<uint8_t>(sv, fits, speculate);
         case 2: return sv_compress_t<uint16_t>(sv, fits, speculate);
         case 4: return sv_compress_t<uint32_t>(sv, fits, speculate);
+        case 5: return sv_compress_t<u32n>(sv, fits, speculate);
     }
     return fail(TD_EINVAL, "bytes per cell must be 1, 2 or 4");
 }
@@ -2542,7 +2606,7 @@ int sv_apply_t(Solver &sv, int r, unsigned long long *keys)
     using PT = typename Tr<CT>::PT;
     ProfScope ps(TD_K_ASSIGN);
     k_assign<PT><<<(sv.n + 255) / 256, 256, 0, c.stream>>>(sv.n, sv.nrows, sv.row0, keys, (PT *)sv.price.p, (int *)sv.owner.p,
-                                                           (int *)sv.r2c.p, (int *)sv.misc.p, r);
+                                                           (int *)sv.r2c.p, (int *)sv.misc.p, r, IsNP<CT>::value ? g_np_plimit : 0ll);
     TD_HIP(hipGetLastError());
     return TD_OK;
 }
@@ -2624,7 +2688,7 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
             for (int b = 0; b < nb; b++) {
                 search();
                 k_pcommit<PT><<<1, 1024, cshm, c.stream>>>(n, (PT *)sv.price.p, (int *)sv.owner.p, r2c_full, (int *)sv.list.p,
-                                                           (int *)sv.misc.p, raise, recs, 0);
+                                                           (int *)sv.misc.p, raise, recs, 0, PS_G, IsNP<CT>::value ? g_np_plimit : 0ll);
             }
             launched += nb;
             TD_HIP(hipGetLastError());
@@ -2795,7 +2859,7 @@ int sv_solve_eps_t(Solver &sv, long long eps0_mult, int theta, int64_t *rounds_o
                                                                                (const PT *)sv.price.p, (const int *)sv.r2c.p, keys,
                                                                                (const int *)sv.misc.p, 60, 1, K, eps);
                 k_assign<PT><<<(n + 255) / 256, 256, 0, c.stream>>>(n, sv.nrows, sv.row0, keys, (PT *)sv.price.p, (int *)sv.owner.p,
-                                                                   (int *)sv.r2c.p, (int *)sv.misc.p, 60);
+                                                                   (int *)sv.r2c.p, (int *)sv.misc.p, 60, IsNP<CT>::value ? g_np_plimit : 0ll);
             }
             rounds += 8;
             k_freelist<<<1, 1024, 0, c.stream>>>(n, (const int *)sv.r2c.p, (int *)sv.list.p, (int *)sv.misc.p);
@@ -2842,7 +2906,7 @@ int sv_warm_t(Solver &sv, int64_t range, int64_t *rounds_out)
                                                                                (const PT *)sv.price.p, (const int *)sv.r2c.p, keys,
                                                                                (const int *)sv.misc.p, 60, 1, 1, eps);
                 k_assign<PT><<<(n + 255) / 256, 256, 0, c.stream>>>(n, sv.nrows, sv.row0, keys, (PT *)sv.price.p, (int *)sv.owner.p,
-                                                                   (int *)sv.r2c.p, (int *)sv.misc.p, 60);
+                                                                   (int *)sv.r2c.p, (int *)sv.misc.p, 60, IsNP<CT>::value ? g_np_plimit : 0ll);
             }
             rounds += 8;
             k_freelist<<<1, 1024, 0, c.stream>>>(n, (const int *)sv.r2c.p, (int *)sv.list.p, (int *)sv.misc.p);
@@ -3083,6 +3147,7 @@ int sv_core_t(Solver &sv, int *ok)
             case 1: rc = CALL<uint8_t>(__VA_ARGS__); break;         \
             case 2: rc = CALL<uint16_t>(__VA_ARGS__); break;        \
             case 4: rc = CALL<uint32_t>(__VA_ARGS__); break;        \
+            case 5: rc = CALL<u32n>(__VA_ARGS__); break;            \
             default: rc = fail(TD_EINVAL, "shard is not compressed yet"); \
         }                                                           \
     } while (0)
@@ -3122,7 +3187,7 @@ int sv_readback(Solver &sv, int64_t *total, int64_t *dual, int max_rounds, int *
     c.stats[1] = 0;
     c.stats[2] = hctl[CTL_NFREE];
     c.stats[3] = hctl[CTL_STEPS];
-    c.stats[4] = sv.bpc;
+    c.stats[4] = sv.bpc == 5 ? 4 : sv.bpc;   // bytes per stored cell (mode 5 = 4-byte cells with 32-bit prices)
     c.stats[5] = hctl[CTL_PACC];
     return TD_OK;
 }
@@ -3164,16 +3229,17 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         return TD_OK;
     }
     const int max_rounds = g_max_rounds;
-    bool solved = false, transposed = false;
+    bool solved = false, transposed = false, np_failed = false;
     int64_t range_hint = -1;
     sv.defer_const = g_defer_const && !g_solver_eps;
     for (int orient = 0; orient < 2 && !solved; orient++) {
     bool want_transpose = false;
     int64_t known_range = transposed ? range_hint : -1;
-    for (int bpc : {1, 2, 4}) {
+    for (int bpc : {1, 2, 5, 4}) {   // 5 = 4-byte cells with 32-bit prices (narrow-price mode, see u32n)
         bool fits = false;
         if (known_range > 254 && bpc == 1) continue;    // the probe's sampled column range: u8 cannot hold it
         if (known_range > 65534 && bpc == 2) continue;  // u16 cannot hold it either
+        if (bpc == 5 && (!g_narrow_price || g_solver_eps || np_failed || known_range < 0 || known_range > NP_RANGE)) continue;
         // the packed bid key keeps (price << 20 | row): prices stay below n * range
         if (known_range >= 0 && (double)(known_range + 1) * (double)(n + 1) >= 4.0e12)
             return fail(TD_ERANGE, "row cost range %lld with n=%d overflows the packed bid key (price < 2^43)",
@@ -3225,6 +3291,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
             const int keep = g_warm_bits;
             g_warm_bits = bits;
             if (bpc == 2) rc = sv_warm_t<uint16_t>(sv, known_range, &warm_rounds);
+            else if (bpc == 5) rc = sv_warm_t<u32n>(sv, known_range, &warm_rounds);
             else rc = sv_warm_t<uint32_t>(sv, known_range, &warm_rounds);
             g_warm_bits = keep;
             return rc;
@@ -3242,7 +3309,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
             wide = !(nfree_now < std::max(g_warm_minfree, n / 64) || (long long)tied0 * 16 * 8 > n);   // tied0 counts every 16th row
             c.stats[2] = nfree_now;
         }
-        if (wide && g_core && n <= 16 * FO_T) {
+        if (wide && g_core && bpc != 5 && n <= 16 * FO_T) {
             // (a) a SHORT eps > 0 schedule (down to range >> TD_CORE_WARM bits) settles the large-scale
             //     price structure: without it the cheapest K cells of a row in a crowded region all
             //     lead to the same few columns and the core holds no perfect matching;
@@ -3294,8 +3361,12 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         TD_DISPATCH(sv, sv_totals_t, sv, dual_bound != nullptr);
         if (rc) return rc;
         int flag = 0;
-        if ((rc = sv_readback(sv, &tot, &dual, max_rounds, spec ? &flag : nullptr))) return rc;
+        if ((rc = sv_readback(sv, &tot, &dual, max_rounds, (spec || bpc == 5) ? &flag : nullptr))) return rc;
         c.stats[1] = warm_rounds;
+        if (bpc == 5 && flag) {   // a price reached the 32-bit limit: the attempt is void, redo with 64-bit prices
+            np_failed = true;
+            continue;
+        }
         if (spec && (flag & 4)) {  // many constant columns: solve the transposed problem instead
             want_transpose = true;
             range_hint = c.stats[6] > 254 ? c.stats[6] : -1;
@@ -3305,6 +3376,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
             known_range = c.stats[6];
             continue;
         }
+        c.stats[6] = (bpc == 5) ? 1 : 0;   // 1: solved in the narrow-price mode
         solved = true;
         break;
     }

@@ -277,3 +277,39 @@ def test_wrappers_refuse_wrong_dtype_or_strided_tensors(td):
     assert total == oracle.assign(c.t().cpu().numpy())[0]
     with pytest.raises(_ffi.TdError):
         td.find_pool(np.array([1, 2, 3]), np.array([2, 3, 4]), torch.zeros((5, 5), dtype=torch.float32, device="cuda"))
+
+
+def test_narrow_price_mode_and_its_fallback(td):
+    """4-byte cells with a small row range are solved with 32-bit prices and labels first; a price at
+    the limit voids the attempt and the solve is redone with 64-bit prices (same optimum).  The limit
+    is lowered through TD_NP_PLIMIT in a child process to force the fallback."""
+    rng = np.random.default_rng(12)
+    n = 1500
+    a, b = rng.integers(0, 10 * n, n), rng.integers(0, 10 * n, n)
+    c = np.abs(a[:, None] - b[None, :]).astype(np.int32)
+    c[:, 0] += 70000                                   # range > 65 534: 4-byte cells
+    ref = oracle.assign(c)[0]
+    r2c, total, dual = td.assign(c, want_dual=True)
+    assert total == ref == dual
+    st = td.last_stats()
+    assert st["bytes_per_cell"] == 4 and st["narrow_price"] == 1
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import taxidispatcher_amd as td
+td.init(0)
+rng = np.random.default_rng(12)
+n = 1500
+a, b = rng.integers(0, 10 * n, n), rng.integers(0, 10 * n, n)
+c = np.abs(a[:, None] - b[None, :]).astype(np.int32)
+c[:, 0] += 70000
+r2c, total, dual = td.assign(c, want_dual=True)
+st = td.last_stats()
+print("RESULT", total, dual, st["bytes_per_cell"], st["narrow_price"])
+''' % ROOT
+    env = dict(os.environ, TD_NP_PLIMIT="2000")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert int(line[1]) == ref == int(line[2])
+    assert line[3] == "4" and line[4] == "0"          # redone with 64-bit prices
