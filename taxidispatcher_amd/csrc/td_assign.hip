@@ -1501,6 +1501,9 @@ constexpr int SX_KMAX = 64;    // workgroups
 #ifndef TD_SX_G
 #define TD_SX_G 8
 #endif
+#ifndef TD_SX_NG
+#define TD_SX_NG 2   // row groups per workgroup of k_sapx for 4-byte cells (measured: 1 -> 1125 ms, 2 -> 1033 ms, 4 -> 1237 ms on the |a-b| N = 16384 instance)
+#endif
 constexpr int SX_G = TD_SX_G;  // rows in flight per relax group
 struct SxSlot {
     long long flabel;   // smallest label among this workgroup's free columns
@@ -1520,8 +1523,13 @@ struct SxShared {
     SxEnt ent[2][SX_KMAX][SX_WL];
 };
 
-template <typename CT, int TX>
-__global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab tab, typename Tr<CT>::PT *__restrict__ pk,
+// NG row groups: the workgroup has NG * TX threads; thread (grp, tid) owns column chunk wg * TX + tid like
+// before, all groups hold the same per-column state, and in the relax phase group g takes every NG-th block
+// of published rows — NG waves per SIMD instead of one hide the latency of the row loads and of the LDS
+// reads (the relax phase was 61 % of a step with one wave per SIMD).  The groups' labels are merged
+// through LDS at the end of the step (minimum; ties -> lowest group), so the state stays replicated.
+template <typename CT, int TX, int NG>
+__global__ __launch_bounds__(TX * NG) void k_sapx(int n, int nchunks, const ShardTab tab, typename Tr<CT>::PT *__restrict__ pk,
                                              int *owner_g, int *__restrict__ r2c, int *pred_g,
                                              const int *__restrict__ list, int *__restrict__ ctl, SxShared *sh)
 {
@@ -1531,6 +1539,7 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
     typedef typename std::conditional<sizeof(PT) == 4, int, long long>::type LT;
     constexpr int E = Tr<CT>::E;
     constexpr int NW = TX / 64;
+    constexpr int SXG = NG >= 4 ? SX_G / 2 : SX_G;   // rows in flight per thread: the register budget halves at 1024 threads
     constexpr LT LMAX = sizeof(LT) == 4 ? (LT)(1 << 30) : (LT)((long long)1 << 62);
     __shared__ LT s_k[NW], s_p[NW], s_f[NW];
     __shared__ int s_j[NW], s_o[NW], s_fj[NW], s_wcnt[NW];
@@ -1542,10 +1551,13 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
     __shared__ int s_ce[SX_KMAX * SX_WL];
     __shared__ int s_off[64];
     __shared__ int s_ok;
+    __shared__ LT s_cd[NG > 1 ? NG * TX * E : 1];    // merge of the row groups' labels
+    __shared__ int s_cc[NG > 1 ? NG * TX * E : 1];   // ... and of the predecessor columns
     if (ctl[CTL_FLAG]) return;
     const int nfree = ctl[CTL_NFREE];
     if (nfree <= 0) return;
-    const int K = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int K = gridDim.x, wg = blockIdx.x, grp = threadIdx.x / TX, tid = threadIdx.x % TX, lane = tid & 63, w = tid >> 6;
+    const bool g0 = grp == 0;   // the group that writes shared / global state
     const int npad = nchunks * E;
     const size_t pitch = (size_t)npad;
     const int ch = wg * TX + tid;
@@ -1566,7 +1578,7 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
     auto grid_sync = [&]() -> bool {
         __threadfence();
         __syncthreads();
-        if (tid == 0) {
+        if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             atomicAdd(&sh->bar, 1ull);
             const unsigned long long target = (epoch + 1ull) * (unsigned long long)K;
@@ -1605,7 +1617,7 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
                 const bool ok = (valid >> e) & 1u;
                 d[e] = ok ? (LT)c[e] + preg[e] : LMAX;
                 dp[e] = ok ? (LT)c[e] : -LMAX;
-                if (ok) pred_g[jbase + e] = -1;
+                if (ok && g0) pred_g[jbase + e] = -1;
                 if (ownr[e] != -1) owned |= 1u << e;
             }
         }
@@ -1638,7 +1650,7 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
                 LT p2 = 0;
                 wave_argmin<LT>(fk, fj, o2, p2);
             }
-            if (lane == 0) {
+            if (g0 && lane == 0) {
                 s_k[w] = bk;
                 s_j[w] = bj;
                 s_o[w] = bo;
@@ -1676,7 +1688,7 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
                 if (lane >= shf) incl += v;
             }
             __syncthreads();   // s_k.. consumed
-            if (lane == 63) s_wcnt[w] = incl;
+            if (g0 && lane == 63) s_wcnt[w] = incl;
             __syncthreads();
             const int head = (bj != INT_MAX) ? 1 : 0;
             int pos = head, tot = head;
@@ -1690,16 +1702,18 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 if (((cand >> e) & 1u) && pos < SX_WL) {
-                    ge[pos].d = d[e];
-                    ge[pos].p = preg[e];
-                    ge[pos].col = jbase + e;
-                    ge[pos].own = ownr[e];
+                    if (g0) {
+                        ge[pos].d = d[e];
+                        ge[pos].p = preg[e];
+                        ge[pos].col = jbase + e;
+                        ge[pos].own = ownr[e];
+                    }
                     scanned |= 1u << e;
                     pos++;
                 }
             }
             if (head && bj >= jbase && bj < jbase + E) scanned |= 1u << (bj - jbase);
-            if (tid == 0) {
+            if (g0 && tid == 0) {
                 if (head) {
                     ge[0].d = bk;
                     ge[0].p = bp;
@@ -1719,7 +1733,7 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
             }
             const long long tc2 = clock64();
             // ---- everybody reads the published step
-            if (tid < K) s_slot[tid] = sh->slot[par][tid];
+            if (g0 && tid < K) s_slot[tid] = sh->slot[par][tid];
             __syncthreads();
             int B = 0;
             LT nF = LMAX;
@@ -1744,7 +1758,7 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
             LT nbase = LMAX;
             {
                 // offsets of the workgroups' entries in the compact list: one wave scan over the counts
-                if (tid < 64) {
+                if (g0 && tid < 64) {
                     const int cq = (tid < K) ? s_slot[tid].cnt : 0;
                     int inc = cq;
 #pragma unroll
@@ -1764,7 +1778,7 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
                 for (int it = 0; it < NIT; it++) {
                     const int t = it * TX + tid;
                     const int q = t / SX_WL, i = t - q * SX_WL;
-                    ok[it] = q < K && i < s_slot[q < K ? q : 0].cnt;
+                    ok[it] = g0 && q < K && i < s_slot[q < K ? q : 0].cnt;
                     if (ok[it]) en[it] = sh->ent[par][q][i];
                 }
                 CT cw[NIT];
@@ -1794,7 +1808,7 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
                 const LT o = __shfl_xor(nbase, shf);
                 nbase = o < nbase ? o : nbase;
             }
-            if (lane == 0) s_k[w] = nbase;
+            if (g0 && lane == 0) s_k[w] = nbase;
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < NW; q++) nbase = s_k[q] < nbase ? s_k[q] : nbase;
@@ -1806,21 +1820,29 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
             // next group are issued before the current group is relaxed (double buffer).
             typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
             typedef const v4u_t __attribute__((address_space(1))) *gvec_t;
-            v4u_t cvn[SX_G];
+            // row group `grp` relaxes the blocks grp, grp + NG, ... of SXG published rows
+            LT dp0[E];
+            int pc[E];
 #pragma unroll
-            for (int g = 0; g < SX_G; g++)
-                cvn[g] = *(gvec_t)(uintptr_t)(s_rp[min(g, B - 1)] + lofs);
-            for (int e0 = 0; e0 < B; e0 += SX_G) {
-                uint4 cv[SX_G];
+            for (int x = 0; x < E; x++) {
+                dp0[x] = dp[x];
+                pc[x] = -1;
+            }
+            v4u_t cvn[SXG];
 #pragma unroll
-                for (int g = 0; g < SX_G; g++) cv[g] = make_uint4(cvn[g].x, cvn[g].y, cvn[g].z, cvn[g].w);
-                if (e0 + SX_G < B) {
+            for (int g = 0; g < SXG; g++)
+                cvn[g] = *(gvec_t)(uintptr_t)(s_rp[min(grp * SXG + g, B - 1)] + lofs);
+            for (int e0 = grp * SXG; e0 < B; e0 += NG * SXG) {
+                uint4 cv[SXG];
 #pragma unroll
-                    for (int g = 0; g < SX_G; g++)
-                        cvn[g] = *(gvec_t)(uintptr_t)(s_rp[min(e0 + SX_G + g, B - 1)] + lofs);
+                for (int g = 0; g < SXG; g++) cv[g] = make_uint4(cvn[g].x, cvn[g].y, cvn[g].z, cvn[g].w);
+                if (e0 + NG * SXG < B) {
+#pragma unroll
+                    for (int g = 0; g < SXG; g++)
+                        cvn[g] = *(gvec_t)(uintptr_t)(s_rp[min(e0 + NG * SXG + g, B - 1)] + lofs);
                 }
 #pragma unroll
-                for (int g = 0; g < SX_G; g++) {
+                for (int g = 0; g < SXG; g++) {
                     const LT bs = s_bs[min(e0 + g, B - 1)];
                     uint32_t c[E];
                     unpack<CT>(cv[g], c);
@@ -1834,15 +1856,45 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
                             const LT t = bs + (LT)c[x];
                             if (t < dp[x]) {
                                 dp[x] = t;
-                                d[x] = t + preg[x];
-                                pred_g[jbase + x] = cg;
-                                scanned &= ~(1u << x);   // (re)opened
+                                pc[x] = cg;
                             }
                         }
                     }
                 }
             }
-            if (wg == 0 && tid == 0) {
+            if constexpr (NG > 1) {
+                // merge the groups' labels: minimum, ties -> lowest group; every group ends with the same state
+#pragma unroll
+                for (int x = 0; x < E; x++) {
+                    s_cd[(grp * TX + tid) * E + x] = dp[x];
+                    s_cc[(grp * TX + tid) * E + x] = pc[x];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int x = 0; x < E; x++) {
+                    LT best = dp0[x];
+                    int bc = -1;
+#pragma unroll
+                    for (int q = 0; q < NG; q++) {
+                        const LT v = s_cd[(q * TX + tid) * E + x];
+                        if (v < best) {
+                            best = v;
+                            bc = s_cc[(q * TX + tid) * E + x];
+                        }
+                    }
+                    dp[x] = best;
+                    pc[x] = bc;
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < E; x++) {
+                if (pc[x] >= 0) {   // improved in this step: (re)opened
+                    d[x] = dp[x] + preg[x];
+                    scanned &= ~(1u << x);
+                    if (g0) pred_g[jbase + x] = pc[x];
+                }
+            }
+            if (wg == 0 && g0 && tid == 0) {
                 const long long tc4 = clock64();
                 sh->dbg[0] += tc2 - tc1;
                 sh->dbg[1] += tc1 - tc0;
@@ -1873,7 +1925,7 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
                     if (preg[e] >= (LT)NP_PLIMIT) atomicOr(&ctl[CTL_FLAG], 8);
                 }
             }
-        if (wg == 0 && tid == 0) {   // flip the path (pred / owner are global; the barrier made them visible)
+        if (wg == 0 && g0 && tid == 0) {   // flip the path (pred / owner are global; the barrier made them visible)
             int j = endcol;
             for (int hop = 0; hop <= n; hop++) {
                 const int pc = pred_g[j];
@@ -1894,8 +1946,8 @@ __global__ __launch_bounds__(TX) void k_sapx(int n, int nchunks, const ShardTab 
     }
 #pragma unroll
     for (int e = 0; e < E; e++)
-        if (has) pk[jbase + e] = (PT)((PT)preg[e] << 1) | (PT)1;
-    if (wg == 0 && tid == 0) {
+        if (has && g0) pk[jbase + e] = (PT)((PT)preg[e] << 1) | (PT)1;
+    if (wg == 0 && g0 && tid == 0) {
         ctl[CTL_NFREE] = nfree;
         ctl[CTL_STEPS] = (int)(steps > INT_MAX ? INT_MAX : steps);
         if (bad) atomicOr(&ctl[CTL_ERR], 16);
@@ -2721,7 +2773,10 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
             const int *a_list = (const int *)sv.list.p;
             SxShared *a_sh = (SxShared *)sv.xbuf.p;
             void *kargs[] = {&a_n, &a_nch, &a_tab, &a_pk, &a_owner, &a_r2c, &a_pred, &a_list, &a_ctl, &a_sh};
-            const hipError_t le = hipLaunchCooperativeKernel((const void *)k_sapx<CT, 256>, dim3(KX), dim3(TXsel), kargs, 0, c.stream);
+            // 4-byte cells: 4 row groups per workgroup (1024 threads, 4 waves per SIMD in the relax phase)
+            constexpr int NGsel = (sizeof(CT) == 4) ? TD_SX_NG : 1;
+            const hipError_t le = hipLaunchCooperativeKernel((const void *)k_sapx<CT, 256, NGsel>, dim3(KX), dim3(TXsel * NGsel), kargs, 0,
+                                                             c.stream);
             if (le == hipSuccess) launched_x = true;
             else (void)hipGetLastError();
         }
