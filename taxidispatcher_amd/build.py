@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, "csrc", f) for f in ("td_core.hip", "td_assign.hip", "td_lcm.hip", "td_pool.hip")]
-HDR = [os.path.join(HERE, "csrc", "td_common.h"), os.path.join(HERE, "csrc", "td_forest.h"), os.path.join(ROOT, "include", "taxidispatcher_amd.h")]
+HDR = [os.path.join(HERE, "csrc", "td_common.h"), os.path.join(ROOT, "include", "taxidispatcher_amd.h")]
 LIB = os.environ.get("TD_LIB_OUT") or os.path.join(HERE, "libtaxidispatcher_amd.so")
 
 
@@ -30,7 +30,7 @@ def build(force=False, verbose=False):
         hipcc = "hipcc"
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
-           "-DTD_BUILDING=1", "-DTD_NT=%s" % os.environ.get("TD_NT", "2"), "-DTD_FOREST_PROF=%s" % os.environ.get("TD_FOREST_PROF", "0"),
+           "-DTD_BUILDING=1", "-DTD_NT=%s" % os.environ.get("TD_NT", "2"),
            "-DTD_SX_G=%s" % os.environ.get("TD_SX_G", "8"), "-DTD_SX_NG=%s" % os.environ.get("TD_SX_NG", "2"), "-o", LIB] + srcs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -158,13 +158,6 @@ int g_psap_worth = 4;       // TD_PSAP_WORTH    rows a batch must commit on aver
 int g_defer_const = 1;      // TD_DEFER_CONST   constant rows sit out the solve (k_place_const)
 int g_shape = 1;            // TD_SHAPE         probe for constant columns and solve the transpose when they dominate
 int g_shape_max_n = 1 << 20; // TD_SHAPE_MAX_N   largest n the probe runs for
-int g_core = 0;             // TD_CORE          1: sparse core + incremental forest for wide rows (n <= 16 384); exact, but measured slower than the dense path on 4 of 5 |a-b| instances at N = 16 384, so off
-int g_core_k = 128;         // TD_CORE_K        core entries per row at the first extraction
-int g_core_cap = 256;       // TD_CORE_CAP      capacity of a row's core list (<= 256)
-int g_core_warm = 0;        // TD_CORE_WARM     eps phases before the core is extracted: down to range >> this (0: none)
-int g_core_iters = 8;       // TD_CORE_ITERS    pricing passes before the dense finisher takes over
-int g_core_stucks = 2;      // TD_CORE_STUCKS   stuck searches that get cells appended and resume; then the dense finisher takes the rest
-int g_core_stuck_free = 64; // TD_CORE_STUCK_FREE ... only when at most this many rows are still free
 int g_narrow_price = 1;     // TD_NARROW_PRICE  4-byte cells with a row range <= 2^22: 32-bit prices and labels first (redone in 64 bits if a price reaches 2^27)
 long long g_np_plimit = NP_PLIMIT;   // TD_NP_PLIMIT  (tests) lower price limit of the narrow-price mode in k_assign / k_pcommit
 int g_solver_eps = 0;       // TD_SOLVER=eps    literal eps-scaling auction (comparison mode)
@@ -199,13 +192,6 @@ void read_tunables()
     if (const char *e = getenv("TD_PSAP_WORTH")) g_psap_worth = std::max(1, atoi(e));
     if (const char *e = getenv("TD_SPECULATE")) g_speculate = atoi(e) != 0;
     if (const char *e = getenv("TD_LDS_GRID")) g_lds_grid = std::max(1, std::min(8, atoi(e)));
-    if (const char *e = getenv("TD_CORE")) g_core = atoi(e) != 0;
-    if (const char *e = getenv("TD_CORE_K")) g_core_k = std::max(2, std::min(256, atoi(e)));
-    if (const char *e = getenv("TD_CORE_CAP")) g_core_cap = std::max(2, std::min(256, atoi(e)));
-    if (const char *e = getenv("TD_CORE_WARM")) g_core_warm = std::max(0, std::min(30, atoi(e)));
-    if (const char *e = getenv("TD_CORE_ITERS")) g_core_iters = std::max(1, atoi(e));
-    if (const char *e = getenv("TD_CORE_STUCKS")) g_core_stucks = std::max(0, atoi(e));
-    if (const char *e = getenv("TD_CORE_STUCK_FREE")) g_core_stuck_free = std::max(0, atoi(e));
     if (const char *e = getenv("TD_NARROW_PRICE")) g_narrow_price = atoi(e) != 0;
     if (const char *e = getenv("TD_NP_PLIMIT")) g_np_plimit = std::max(1ll, std::min((long long)NP_PLIMIT, atoll(e)));
     if (const char *e = getenv("TD_SOLVER")) g_solver_eps = (strcmp(e, "eps") == 0);
@@ -2477,8 +2463,6 @@ __global__ __launch_bounds__(256) void k_dual(int n, int nrows, int row0, int nc
     if (lane == 0 && acc != 0) atomicAdd(&out[1], (unsigned long long)acc);
 }
 
-#include "td_forest.h"
-
 // -------------------------------------------------------------------------------------
 // host side: one Solver per cost matrix (td_assign) or per row shard (td_shard_*)
 // -------------------------------------------------------------------------------------
@@ -2492,17 +2476,13 @@ struct td_shard {
     int nchunks = 0, npad = 0;
     const int32_t *d_cost = nullptr;  // nrows x n, device
     Buf stage, cc, price, owner, r2c, r2c_full, bid, pred, list, rowmin, rconst, misc, psrec, tbuf, xbuf;
-    Buf f_col, f_val, f_cnt, f_tptr, f_tcur, f_trow, f_tval, f_row, f_pr, f_rootc, f_acol, f_claim, f_stat;   // sparse core + forest (td_forest.h)
-    Buf f_c2row, f_c2val, f_c2cnt, f_xptr, f_xcur, f_xcol, f_xval, f_infc, f_rootr, f_svs, f_svp, f_cold;
     bool defer_const = false;  // constant rows sit out the solve and take the left-over columns (td_assign only)
     int nconst = -1;                 // constant rows counted by the last compress pass (-1: not read back)
     const int32_t *probe = nullptr;  // non-null for the one k_init_state launch that carries the shape probe
     bool placed = false;       // ... and the finisher kernel has already placed them (no k_place_const launch)
     void free_all()
     {
-        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &rconst, &misc, &psrec, &tbuf, &xbuf,
-                     &f_col, &f_val, &f_cnt, &f_tptr, &f_tcur, &f_trow, &f_tval, &f_row, &f_pr, &f_rootc, &f_acol, &f_claim, &f_stat,
-                     &f_c2row, &f_c2val, &f_c2cnt, &f_xptr, &f_xcur, &f_xcol, &f_xval, &f_infc, &f_rootr, &f_svs, &f_svp, &f_cold};
+        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &rconst, &misc, &psrec, &tbuf, &xbuf};
         for (Buf *b : bs) {
             if (b->p) (void)hipFree(b->p);
             b->p = nullptr;
@@ -2980,222 +2960,6 @@ int sv_warm_t(Solver &sv, int64_t range, int64_t *rounds_out)
 }
 
 
-// Sparse core + incremental forest (td_forest.h).  *ok = 1: every row is matched, the prices are
-// dual feasible on the DENSE matrix (priced out) and the matched cells are tight, i.e. optimal.
-// *ok = 0: gave up (error / too many refreshes); the caller restarts with the dense finisher.
-template <typename CT>
-int sv_core_t(Solver &sv, int *ok)
-{
-    Ctx &c = ctx();
-    using PT = typename Tr<CT>::PT;
-    constexpr int E = Tr<CT>::E;
-    *ok = 0;
-    const int n = sv.n, nchunks = sv.nchunks;
-    if (n > 16 * FO_T || n >= 65535) return TD_OK;
-    const int kcap = g_core_cap;
-    const int K = std::min(g_core_k, kcap);
-    int NPT = 1;
-    while (NPT * FO_T < n) NPT *= 2;
-    int CHK = 1;
-    while (CHK * 256 < nchunks) CHK *= 2;
-    if (CHK * E > 64) return TD_OK;
-    int rc;
-    const size_t ne = (size_t)n * kcap;
-    if ((rc = ensure(sv.f_col, sizeof(int) * ne))) return rc;
-    if ((rc = ensure(sv.f_val, sizeof(uint32_t) * ne))) return rc;
-    if ((rc = ensure(sv.f_cnt, sizeof(int) * (size_t)n))) return rc;
-    if ((rc = ensure(sv.f_tptr, sizeof(int) * (size_t)(n + 1)))) return rc;
-    if ((rc = ensure(sv.f_tcur, sizeof(int) * (size_t)(n + 1)))) return rc;
-    if ((rc = ensure(sv.f_trow, sizeof(int) * ne))) return rc;
-    if ((rc = ensure(sv.f_tval, sizeof(uint32_t) * ne))) return rc;
-    if ((rc = ensure(sv.f_row, sizeof(FRow) * (size_t)n))) return rc;
-    if ((rc = ensure(sv.f_pr, sizeof(long long) * (size_t)n))) return rc;
-    if ((rc = ensure(sv.f_rootc, sizeof(int) * (size_t)n))) return rc;
-    if ((rc = ensure(sv.f_acol, sizeof(uint32_t) * (size_t)n))) return rc;
-    if ((rc = ensure(sv.f_claim, sizeof(int) * (size_t)n))) return rc;
-    if ((rc = ensure(sv.f_stat, sizeof(int) * FS_WORDS))) return rc;
-    const size_t ne2 = (size_t)n * FO_KC;
-    if ((rc = ensure(sv.f_c2row, sizeof(int) * ne2))) return rc;
-    if ((rc = ensure(sv.f_c2val, sizeof(uint32_t) * ne2))) return rc;
-    if ((rc = ensure(sv.f_c2cnt, sizeof(int) * (size_t)n))) return rc;
-    if ((rc = ensure(sv.f_xptr, sizeof(int) * (size_t)(n + 1)))) return rc;
-    if ((rc = ensure(sv.f_xcur, sizeof(int) * (size_t)(n + 1)))) return rc;
-    if ((rc = ensure(sv.f_xcol, sizeof(int) * ne2))) return rc;
-    if ((rc = ensure(sv.f_xval, sizeof(uint32_t) * ne2))) return rc;
-    if ((rc = ensure(sv.f_infc, (size_t)n + 16))) return rc;
-    if ((rc = ensure(sv.f_rootr, sizeof(int) * (size_t)n))) return rc;
-    if ((rc = ensure(sv.f_svs, sizeof(uint32_t) * (size_t)n))) return rc;
-    if ((rc = ensure(sv.f_svp, sizeof(uint16_t) * (size_t)n + 16))) return rc;
-    if ((rc = ensure(sv.f_cold, sizeof(int) * (size_t)n))) return rc;
-    int *fs = (int *)sv.f_stat.p;
-    TD_HIP(hipMemsetAsync(fs, 0, sizeof(int) * FS_WORDS, c.stream));
-    TD_HIP(hipMemsetAsync(sv.f_row.p, 0, sizeof(FRow) * (size_t)n, c.stream));
-    auto extract = [&](int mode) -> int {
-        ProfScope ps(TD_K_COMPRESS);
-        const int grid = std::max(1, std::min(n, c.n_cu * 4));
-#define TD_CX(CHKV)                                                                                                         \
-    if constexpr (CHKV * E <= 64)                                                                                           \
-        k_core_extract<CT, CHKV><<<grid, 256, 0, c.stream>>>(n, nchunks, (const CT *)sv.cc.p, (PT *)sv.price.p,             \
-                                                             (int *)sv.owner.p, (int *)sv.r2c.p, (FRow *)sv.f_row.p,        \
-                                                             (int *)sv.f_col.p, (uint32_t *)sv.f_val.p, (int *)sv.f_cnt.p,  \
-                                                             kcap, (mode == 2 ? std::max(16, K / 4) : K), mode, fs, (const unsigned char *)sv.f_infc.p, (int *)sv.f_cold.p)
-        switch (CHK) {
-            case 1: TD_CX(1); break;
-            case 2: TD_CX(2); break;
-            case 4: TD_CX(4); break;
-            case 8: TD_CX(8); break;
-            default: TD_CX(16); break;
-        }
-#undef TD_CX
-        TD_HIP(hipGetLastError());
-        return TD_OK;
-    };
-    auto build_csc = [&]() -> int {
-        TD_HIP(hipMemsetAsync(sv.f_tcur.p, 0, sizeof(int) * (size_t)(n + 1), c.stream));
-        const int grid = std::max(1, std::min((n + 3) / 4, c.n_cu * 8));
-        k_csc_count<<<grid, 256, 0, c.stream>>>(n, kcap, (const int *)sv.f_col.p, (const int *)sv.f_cnt.p, (int *)sv.f_tcur.p);
-        k_csc_scan<<<1, 1024, 0, c.stream>>>(n, (const int *)sv.f_tcur.p, (int *)sv.f_tptr.p, (int *)sv.f_tcur.p);
-        k_csc_fill<<<grid, 256, 0, c.stream>>>(n, kcap, (const int *)sv.f_col.p, (const uint32_t *)sv.f_val.p, (const int *)sv.f_cnt.p,
-                                               (int *)sv.f_tcur.p, (int *)sv.f_trow.p, (uint32_t *)sv.f_tval.p);
-        TD_HIP(hipGetLastError());
-        return TD_OK;
-    };
-    auto build_cols = [&]() -> int {   // column coverage lists + their row view (built once, at the first prices)
-        ProfScope ps(TD_K_COMPRESS);
-        k_core_cols<CT, FO_KC><<<(n + 63) / 64, 256, 0, c.stream>>>(n, nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
-                                                                    (const FRow *)sv.f_row.p, (int *)sv.f_c2row.p,
-                                                                    (uint32_t *)sv.f_c2val.p, (int *)sv.f_c2cnt.p);
-        TD_HIP(hipMemsetAsync(sv.f_xcur.p, 0, sizeof(int) * (size_t)(n + 1), c.stream));
-        const int grid = std::max(1, std::min((n + 3) / 4, c.n_cu * 8));
-        k_csc_count<<<grid, 256, 0, c.stream>>>(n, FO_KC, (const int *)sv.f_c2row.p, (const int *)sv.f_c2cnt.p, (int *)sv.f_xcur.p);
-        k_csc_scan<<<1, 1024, 0, c.stream>>>(n, (const int *)sv.f_xcur.p, (int *)sv.f_xptr.p, (int *)sv.f_xcur.p);
-        k_csc_fill<<<grid, 256, 0, c.stream>>>(n, FO_KC, (const int *)sv.f_c2row.p, (const uint32_t *)sv.f_c2val.p,
-                                               (const int *)sv.f_c2cnt.p, (int *)sv.f_xcur.p, (int *)sv.f_xcol.p, (uint32_t *)sv.f_xval.p);
-        TD_HIP(hipGetLastError());
-        return TD_OK;
-    };
-    ForestArgs A{};
-    A.n = n;
-    A.kcap = kcap;
-    A.c2row = (const int *)sv.f_c2row.p;
-    A.c2val = (const uint32_t *)sv.f_c2val.p;
-    A.c2cnt = (const int *)sv.f_c2cnt.p;
-    A.xptr = (const int *)sv.f_xptr.p;
-    A.xcol = (const int *)sv.f_xcol.p;
-    A.xval = (const uint32_t *)sv.f_xval.p;
-    A.pr = (long long *)sv.f_pr.p;
-    A.pk = sv.price.p;
-    A.owner = (int *)sv.owner.p;
-    A.r2c = (int *)sv.r2c.p;
-    A.rowrec = (FRow *)sv.f_row.p;
-    A.ccol = (const int *)sv.f_col.p;
-    A.cval = (const uint32_t *)sv.f_val.p;
-    A.ccnt = (const int *)sv.f_cnt.p;
-    A.tptr = (const int *)sv.f_tptr.p;
-    A.trow = (const int *)sv.f_trow.p;
-    A.tval = (const uint32_t *)sv.f_tval.p;
-    A.rootc = (int *)sv.f_rootc.p;
-    A.rootr = (int *)sv.f_rootr.p;
-    A.acol = (uint32_t *)sv.f_acol.p;
-    A.claim = (int *)sv.f_claim.p;
-    A.flist = (int *)sv.list.p;
-    A.infc = (unsigned char *)sv.f_infc.p;
-    A.sv_slack = (uint32_t *)sv.f_svs.p;
-    A.sv_pred = (uint16_t *)sv.f_svp.p;
-    A.cold = (const int *)sv.f_cold.p;
-    A.resume = 0;
-    A.fs = fs;
-    const size_t np = (size_t)NPT * FO_T;
-    const size_t shm = np * 4 + np * 2 + np * 2 + np / 8 + FO_LIST * 2 * 2 + FO_LIST * 4 + FO_REP * 2;
-    auto forest = [&]() -> int {
-        ProfScope ps(TD_K_SAP);
-#define TD_FO(NPTV)                                                                                                  \
-    {                                                                                                                \
-        if (shm > 48 * 1024)                                                                                         \
-            (void)hipFuncSetAttribute((const void *)k_forest<PT, NPTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-        k_forest<PT, NPTV><<<1, FO_T, shm, c.stream>>>(A);                                                            \
-    }
-        switch (NPT) {
-            case 1: TD_FO(1); break;
-            case 2: TD_FO(2); break;
-            case 4: TD_FO(4); break;
-            case 8: TD_FO(8); break;
-            default: TD_FO(16); break;
-        }
-#undef TD_FO
-        TD_HIP(hipGetLastError());
-        return TD_OK;
-    };
-    auto read_fs = [&](int *h) -> int {
-        TD_HIP(hipMemcpyAsync(c.pinned, fs, sizeof(int) * FS_WORDS, hipMemcpyDeviceToHost, c.stream));
-        TD_HIP(hipStreamSynchronize(c.stream));
-        memcpy(h, c.pinned, sizeof(int) * FS_WORDS);
-        return TD_OK;
-    };
-    if ((rc = extract(0))) return rc;
-    if ((rc = build_cols())) return rc;
-    int h[FS_WORDS];
-    int iters = 0, checks = 0, stucks = 0;
-    const bool dbg = getenv("TD_DEBUG") != nullptr;
-    int result = 1;   // 1: solved and priced out; 2: rows left for the dense finisher (state valid on the dense matrix)
-    for (;; iters++) {
-        if ((rc = build_csc())) return rc;
-        if ((rc = forest())) return rc;
-        if ((rc = read_fs(h))) return rc;
-        if (dbg)
-            fprintf(stderr, "[td] forest launch %d%s: status %d free %d | levels %d joins %d repairs %d events %d augs %d err %d | kcyc argmin+list %d join %d release %d repair %d relax %d\n", iters,
-                    A.resume ? " (resumed)" : "", h[FS_STATUS], h[FS_NFREE], h[FS_LEVELS], h[FS_JOINS], h[FS_REPAIRS], h[FS_EVENTS], h[FS_AUGS], h[FS_ERRCODE],
-                    h[10], h[11], h[12], h[13], h[14]);
-        if (h[FS_STATUS] == 2 || (h[FS_ERRCODE] && h[FS_ERRCODE] != 9)) return TD_OK;   // *ok stays 0: start over, dense path
-        bool give_up = false;
-        if (h[FS_STATUS] == 1) {
-            // No reachable column inside the core.  A few times the rows of the forest get their
-            // cheapest cells outside it and the search resumes; rows that need long detours through
-            // cells the core does not hold (the last 1-2 % in the |a-b| geometry) are left to the
-            // dense finisher, which continues from the same duals.
-            if (stucks < g_core_stucks && h[FS_ERRCODE] != 9 && h[FS_NFREE] <= g_core_stuck_free) {
-                stucks++;
-                if ((rc = extract(2))) return rc;
-                A.resume = 1;
-                continue;
-            }
-            if (h[FS_NFREE] > g_core_stuck_free) {
-                // many rows left whose paths the core does not hold: its duals are far from feasible on
-                // the dense matrix by now.  Keep the PRICES only (any non-negative price vector is dual
-                // feasible): they serve as the warm start of the dense path.
-                result = 3;
-                break;
-            }
-            give_up = true;
-        }
-        A.resume = 0;
-        // Price out against the dense matrix: rows whose dense minimum of c + p lies below their core
-        // dual get the dense minimum as dual and, when their matched cell is not tight any more, are
-        // freed.  Afterwards every dual is feasible on the dense matrix and every matched cell tight.
-        TD_HIP(hipMemsetAsync(fs + FS_VIOL, 0, sizeof(int), c.stream));
-        TD_HIP(hipMemsetAsync(fs + FS_ERRCODE, 0, sizeof(int), c.stream));
-        if ((rc = extract(1))) return rc;
-        if ((rc = read_fs(h))) return rc;
-        checks++;
-        if (dbg) fprintf(stderr, "[td] pricing pass %d: %d rows violate%s\n", checks, h[FS_VIOL], give_up ? " (rest goes to the dense finisher)" : "");
-        if (give_up || (h[FS_VIOL] != 0 && checks >= g_core_iters)) {
-            result = 2;
-            break;
-        }
-        if (h[FS_VIOL] == 0) break;
-    }
-    c.stats[8] = h[FS_LEVELS];
-    c.stats[9] = h[FS_JOINS];
-    c.stats[10] = h[FS_REPAIRS];
-    c.stats[11] = h[FS_EVENTS];
-    c.stats[12] = iters + 1;
-    c.stats[13] = checks;
-    c.stats[14] = h[FS_REFRESH];
-    c.stats[15] = h[FS_AUGS];
-    *ok = result;
-    return TD_OK;
-}
-
 #define TD_DISPATCH(sv, CALL, ...)                                  \
     do {                                                            \
         switch ((sv).bpc) {                                         \
@@ -3313,8 +3077,6 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         sv.probe = nullptr;
         if (rc) return rc;
         int64_t warm_rounds = 0;
-        bool core_done = false, core_partial = false;
-        for (int q = 8; q < 16; q++) c.stats[q] = 0;
         if (g_solver_eps) {
             int64_t er = 0, ep = 0;
             TD_DISPATCH(sv, sv_solve_eps_t, sv, g_eps0_mult, g_eps_theta, &er, &ep);
@@ -3364,36 +3126,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
             wide = !(nfree_now < std::max(g_warm_minfree, n / 64) || (long long)tied0 * 16 * 8 > n);   // tied0 counts every 16th row
             c.stats[2] = nfree_now;
         }
-        if (wide && g_core && bpc != 5 && n <= 16 * FO_T) {
-            // (a) a SHORT eps > 0 schedule (down to range >> TD_CORE_WARM bits) settles the large-scale
-            //     price structure: without it the cheapest K cells of a row in a crowded region all
-            //     lead to the same few columns and the core holds no perfect matching;
-            // (b) eps = 0 rounds at those prices, (c) sparse core + incremental forest (td_forest.h),
-            //     exact and priced out on the dense matrix.
-            if (g_core_warm > 0) {
-                if ((rc = warm(g_core_warm))) return rc;
-                if ((rc = rounds(false))) return rc;
-            }
-            int ok = 0;
-            if (bpc == 2) rc = sv_core_t<uint16_t>(sv, &ok);
-            else rc = sv_core_t<uint32_t>(sv, &ok);
-            if (rc) return rc;
-            core_done = ok == 1;
-            core_partial = ok == 2 || ok == 3;   // 2: most rows matched, duals feasible on the dense matrix: the dense finisher does the rest
-            if (ok == 3) {   // only the prices of the forest are kept: eps = 0 rounds at those prices, then the dense finisher
-                using P8 = int64_t;
-                k_eps_reset<P8><<<(std::max(n, (int)CTL_WORDS) + 255) / 256, 256, 0, c.stream>>>(n, sv.nrows, (P8 *)sv.price.p, (int *)sv.owner.p,
-                                                                                              (int *)sv.r2c.p, (int *)sv.misc.p);
-                if ((rc = rounds(false))) return rc;
-            }
-            if (ok == 0) {   // error: start again from clean prices, the dense path below takes over
-                TD_DISPATCH(sv, sv_begin_t, sv);
-                if (rc) return rc;
-                if ((rc = rounds(false))) return rc;
-                warm_rounds = 0;
-            }
-        }
-        if (wide && !core_done && !core_partial) {
+        if (wide) {
             // eps > 0 phases down to eps = 1 as a price warm start (sv_warm_t), the rounds once more,
             // then the dense finisher
             if ((rc = warm(g_warm_bits))) return rc;
@@ -3404,10 +3137,8 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         tab.rps = n;
         tab.count = 1;
         sv.placed = false;
-        if (!core_done) {
-            TD_DISPATCH(sv, sv_finish_t, sv, tab, (int *)sv.r2c.p);
-            if (rc) return rc;
-        }
+        TD_DISPATCH(sv, sv_finish_t, sv, tab, (int *)sv.r2c.p);
+        if (rc) return rc;
         if (sv.defer_const && !sv.placed) {
             ProfScope ps(TD_K_FINAL);
             k_place_const<<<1, 1024, 0, c.stream>>>(n, (int *)sv.r2c.p, (int *)sv.owner.p, (int *)sv.list.p, (int *)sv.pred.p,

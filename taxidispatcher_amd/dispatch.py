@@ -121,9 +121,6 @@ def last_stats():
     _ffi.check(_ffi.lib().td_last_stats(out, 16))
     d = {"bid_rounds": out[0], "warm_rounds": out[1], "sap_free_rows": out[2], "sap_steps": out[3], "bytes_per_cell": out[4],
          "parallel_sap_rows": out[5], "narrow_price": out[6], "transposed": out[7]}
-    if out[12]:   # the sparse-core + forest finisher ran (csrc/td_forest.h)
-        d["forest"] = {"levels": out[8], "row_joins": out[9], "label_repairs": out[10], "release_events": out[11],
-                       "launches": out[12], "pricing_passes": out[13], "rows_refreshed": out[14], "augmentations": out[15]}
     return d
 
 

@@ -252,17 +252,6 @@ def test_count_sum_single_row(td):
     assert td.count_sum(1, np.array([[BIG]], np.int32), np.array([1])) == 0
 
 
-def test_sparse_core_forest_path(td):
-    """TD_CORE=1 (csrc/td_forest.h): the sparse-core + incremental-forest finisher is off by default
-    (measured slower on most |a-b| instances) but must stay exact; tunables are read once per
-    process, so it runs in a child."""
-    env = dict(os.environ, TD_CORE="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_forest.py"), "300", "1000", "2048", "4096"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "'forest'" in r.stdout and "FAILURES: 0" in r.stdout
-
-
 def test_wrappers_refuse_wrong_dtype_or_strided_tensors(td):
     """torch CUDA tensors go to the kernels as they are, so the wrappers check them."""
     import torch
