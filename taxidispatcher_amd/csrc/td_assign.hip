@@ -1559,6 +1559,11 @@ __global__ __launch_bounds__(TX * NG) void k_sapx(int n, int nchunks, const Shar
         preg[e] = has ? (LT)(pk[jbase + e] >> 1) : 0;   // pad columns keep their (huge) price
         ownr[e] = ok ? owner_g[jbase + e] : -2;
     }
+    // cost of every owned column in its owner's row: with the price it is the owner's row dual, which a
+    // published column carries along (the consumers then need no second, dependent load per entry)
+    LT cown[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) cown[e] = (ownr[e] >= 0) ? (LT)shard_row<CT>(tab, ownr[e], pitch)[jbase + e] : 0;
     unsigned long long epoch = 0;
     // grid barrier; false = some workgroup gave up (abort raised)
     auto grid_sync = [&]() -> bool {
@@ -1623,7 +1628,7 @@ __global__ __launch_bounds__(TX * NG) void k_sapx(int n, int nchunks, const Shar
                     bk = d[e];
                     bj = jbase + e;
                     bo = ownr[e];
-                    bp = preg[e];
+                    bp = cown[e] + preg[e];
                 }
                 if (((valid >> e) & 1u) && !ow && d[e] < fk) {
                     fk = d[e];
@@ -1690,7 +1695,7 @@ __global__ __launch_bounds__(TX * NG) void k_sapx(int n, int nchunks, const Shar
                 if (((cand >> e) & 1u) && pos < SX_WL) {
                     if (g0) {
                         ge[pos].d = d[e];
-                        ge[pos].p = preg[e];
+                        ge[pos].p = cown[e] + preg[e];   // the owner's row dual
                         ge[pos].col = jbase + e;
                         ge[pos].own = ownr[e];
                     }
@@ -1755,8 +1760,8 @@ __global__ __launch_bounds__(TX * NG) void k_sapx(int n, int nchunks, const Shar
                     s_off[tid] = inc - cq;
                 }
                 __syncthreads();
-                // all entry loads of a thread are issued together, then all row-dual loads: two
-                // memory round trips per step however many entries a thread has to fetch
+                // all entry loads of a thread are issued together: one memory round trip per step
+                // however many entries a thread has to fetch (the entries carry the owner's row dual)
                 constexpr int NIT = (SX_KMAX * SX_WL + TX - 1) / TX;
                 SxEnt en[NIT];
                 bool ok[NIT];
@@ -1767,22 +1772,17 @@ __global__ __launch_bounds__(TX * NG) void k_sapx(int n, int nchunks, const Shar
                     ok[it] = g0 && q < K && i < s_slot[q < K ? q : 0].cnt;
                     if (ok[it]) en[it] = sh->ent[par][q][i];
                 }
-                CT cw[NIT];
                 const CT *rps[NIT];
 #pragma unroll
-                for (int it = 0; it < NIT; it++) {
-                    if (ok[it]) {
-                        rps[it] = shard_row<CT>(tab, en[it].own, pitch);
-                        cw[it] = rps[it][en[it].col];
-                    }
-                }
+                for (int it = 0; it < NIT; it++)
+                    if (ok[it]) rps[it] = shard_row<CT>(tab, en[it].own, pitch);
 #pragma unroll
                 for (int it = 0; it < NIT; it++) {
                     if (ok[it]) {
                         const int t = it * TX + tid;
                         const int q = t / SX_WL, i = t - q * SX_WL;
                         const int at = s_off[q] + i;
-                        s_bs[at] = en[it].d - ((LT)cw[it] + en[it].p);   // label minus the owner's row dual
+                        s_bs[at] = en[it].d - en[it].p;   // label minus the owner's row dual
                         s_rp[at] = rps[it] + (size_t)wg * TX * E;
                         s_ce[at] = en[it].col;
                         nbase = en[it].d < nbase ? en[it].d : nbase;
@@ -1928,7 +1928,13 @@ __global__ __launch_bounds__(TX * NG) void k_sapx(int n, int nchunks, const Shar
         }
 #pragma unroll
         for (int e = 0; e < E; e++)
-            if ((valid >> e) & 1u) ownr[e] = owner_g[jbase + e];
+            if ((valid >> e) & 1u) {
+                const int no = owner_g[jbase + e];
+                if (no != ownr[e]) {   // a column of the augmenting path
+                    ownr[e] = no;
+                    cown[e] = (no >= 0) ? (LT)shard_row<CT>(tab, no, pitch)[jbase + e] : 0;
+                }
+            }
     }
 #pragma unroll
     for (int e = 0; e < E; e++)
