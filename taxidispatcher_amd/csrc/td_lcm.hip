@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256) void k_lcms_minmax(int n, const int32_t *__res
 }
 
 // one wavefront per row; SCATTER = false: count per level, true: write the cells
+constexpr int LCH = 16;
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_lcms_rows(int n, const int32_t *__restrict__ cost, int64_t hi, int vmin, int nlev,
                                                    int *__restrict__ rowcnt /* [nlev][n] counts, then offsets */,
@@ -319,9 +320,21 @@ __global__ __launch_bounds__(256) void k_lcms_rows(int n, const int32_t *__restr
     for (int row = blockIdx.x * nw + w; row < n; row += gridDim.x * nw) {
         for (int l = lane; l < nlev; l += 64) s_cnt[w][l] = SCATTER ? rowcnt[(size_t)l * n + row] : 0;
         const int32_t *rp = cost + (int64_t)row * n;
-        for (int j0 = 0; j0 < n; j0 += 64) {
+        // 16 chunks of 64 cells are loaded together (one memory round trip per 1024 cells instead of
+        // one per 64: the scan of a row is a dependent chain, a 1300-cell row took 21 round trips)
+        for (int jb = 0; jb < n; jb += 64 * LCH) {
+          int vv[LCH];
+#pragma unroll
+          for (int u = 0; u < LCH; u++) {
+              const int j = jb + 64 * u + lane;
+              vv[u] = (j < n) ? rp[j] : 0;
+          }
+#pragma unroll
+          for (int u = 0; u < LCH; u++) {
+            const int j0 = jb + 64 * u;
+            if (j0 >= n) break;
             const int j = j0 + lane;
-            const int v = (j < n) ? rp[j] : 0;
+            const int v = vv[u];
             int lv = (j < n && (int64_t)v <= hi) ? v - vmin : -1;
             unsigned long long act = __ballot(lv >= 0);
             while (act) {
@@ -338,6 +351,7 @@ __global__ __launch_bounds__(256) void k_lcms_rows(int n, const int32_t *__restr
                 if (lv == cur) lv = -1;
                 act &= ~m;
             }
+          }
         }
         if (!SCATTER)
             for (int l = lane; l < nlev; l += 64) rowcnt[(size_t)l * n + row] = s_cnt[w][l];
