@@ -143,3 +143,27 @@ def test_lcm_sharded_bit_identical_to_td_lcm(td):
                 for s in shards:
                     s.close()
             assert tot == ref[0] and rows == ref[1].tolist() and cols == ref[2].tolist() and lm == ref[3], (n, world)
+
+
+@pytest.mark.gpu
+def test_bench_sharded_leg_through_rccl(td):
+    """The multi-GPU leg of bench.py with one rank: process group on the nccl backend, the library's
+    own RCCL communicator (td_comm_init), td_shard_rounds, finisher, totals — and the JSON contract."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-sharded", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extras", "--sharded-n", "8192", "--n", "4096"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["total_cost"] == 10 * 4096
+    sh = line["sharded_single_instance"]
+    assert "error" not in sh, sh
+    assert sh["optimal"] and sh["total_cost"] == 10 * 8192 and sh["speedup_vs_single_gpu"] > 0
