@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
            "-DTD_BUILDING=1", "-DTD_NT=%s" % os.environ.get("TD_NT", "2"),
-           "-DTD_SX_G=%s" % os.environ.get("TD_SX_G", "8"), "-DTD_SX_NG=%s" % os.environ.get("TD_SX_NG", "2"), "-o", LIB] + srcs
+           "-DTD_SX_G=%s" % os.environ.get("TD_SX_G", "8"), "-DTD_SX_NG=%s" % os.environ.get("TD_SX_NG", "2"), "-DTD_SX_TX=%s" % os.environ.get("TD_SX_TX", "128"), "-o", LIB] + srcs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)

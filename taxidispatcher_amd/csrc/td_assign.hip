@@ -2742,7 +2742,10 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
         // workgroup resident at the same time, which an ordinary launch does not promise when other
         // streams or processes share the GPU.  If the cooperative launch is refused the
         // single-workgroup finisher below does the job.
-        constexpr int TXsel = 256;
+#ifndef TD_SX_TX
+#define TD_SX_TX 128
+#endif
+        constexpr int TXsel = (sizeof(CT) == 4) ? TD_SX_TX : 256;
         const int KX = (nchunks + TXsel - 1) / TXsel;
         const bool lean8 = sizeof(CT) == 1 && CH == 1 && g_sap8;
         bool launched_x = false;
@@ -2761,7 +2764,7 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
             void *kargs[] = {&a_n, &a_nch, &a_tab, &a_pk, &a_owner, &a_r2c, &a_pred, &a_list, &a_ctl, &a_sh};
             // 4-byte cells: 4 row groups per workgroup (1024 threads, 4 waves per SIMD in the relax phase)
             constexpr int NGsel = (sizeof(CT) == 4) ? TD_SX_NG : 1;
-            const hipError_t le = hipLaunchCooperativeKernel((const void *)k_sapx<CT, 256, NGsel>, dim3(KX), dim3(TXsel * NGsel), kargs, 0,
+            const hipError_t le = hipLaunchCooperativeKernel((const void *)k_sapx<CT, TXsel, NGsel>, dim3(KX), dim3(TXsel * NGsel), kargs, 0,
                                                              c.stream);
             if (le == hipSuccess) launched_x = true;
             else (void)hipGetLastError();
