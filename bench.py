@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--multi-mode", default="sharded", choices=["sharded", "replicas"],
                     help="headline of a multi-GPU run: the row-sharded single instance (configs[3]) or replicas")
+    ap.add_argument("--line-metric", default="on", choices=["on", "off"],
+                    help="off: td_set_line_metric(0), the general solver alone (matters for g2, whose |a-b| matrix the "
+                         "default path answers with the sorted matching + certificate pass)")
     ap.add_argument("--no-extras", action="store_true", help="skip the g2 / g3 / tick side measurements (1 GPU)")
     return ap.parse_args()
 
@@ -296,7 +299,7 @@ def pmc_traffic(kernel_class):
     FETCH_SIZE doubled per MI355X_MICROARCH.md).  Not measured in this run: the line carries the
     file name as `traffic_source`.  None if the summary is missing."""
     prefix = {"compress": "k_compress", "gen": "k_gen_uniform", "cost_build": "k_cost_build", "bid": "k_bid",
-              "sap": "k_sap", "assign": "k_assign", "final": "k_final", "lcm": "k_lcm"}.get(kernel_class)
+              "sap": "k_sap", "assign": "k_assign", "final": "k_final", "lcm": "k_lcm", "cert": "k_line_cert"}.get(kernel_class)
     path = os.path.join(ROOT, TRAFFIC_PROFILE)
     if not os.path.exists(path) or not prefix:
         return None
@@ -360,6 +363,7 @@ def main():
     import taxidispatcher_amd as td
     from taxidispatcher_amd import _ffi as ffi
     td.init(local)
+    td.set_line_metric(args.line_metric == "on")
     # the library runs on its own stream; the timed region is bracketed by device-wide synchronisation
 
     if args.workload == "tick":
@@ -414,7 +418,8 @@ def main():
     # streaming kernel (cost write, compress, LCM) are compared directly; "bid" / "assign" / "sap"
     # are many launches of several different kernels (the largest single one, bidding round 0, is
     # ~1/3 of compress), so they are reported as a class but never priced as one kernel.
-    alg_bytes = {"gen": 4.0 * n * n, "cost_build": 4.0 * n * n, "compress": 4.0 * n * n, "lcm": 4.0 * n * n}
+    alg_bytes = {"gen": 4.0 * n * n, "cost_build": 4.0 * n * n, "compress": 4.0 * n * n, "lcm": 4.0 * n * n,
+                 "cert": 4.0 * n * n}   # cert = the certificate pass of the line-metric path (td_line.hip): one read of the matrix
     streaming = [k for k in prof if k in alg_bytes and prof[k]["launches"] <= 2]
     dom = max(streaming, key=lambda k: prof[k]["total_ms"]) if streaming else None
     roof = None
@@ -437,6 +442,8 @@ def main():
         "whole_step_algorithmic_GBps": 8.0 * n * n * world * args.steps / dt / 1e9,
         "total_cost": int(total), "solver_stats": stats, "kernels": prof, "roofline": roof,
     }
+    if args.line_metric == "off":
+        line["config"]["line_metric_attempt"] = "off"
     if shard_res is not None:
         line["sharded_single_instance"] = shard_res
         if world > 1 and args.multi_mode == "sharded" and "error" not in shard_res:
@@ -456,8 +463,12 @@ def main():
         extras = {}
         del wl.cost
         torch.cuda.empty_cache()
-        for name, kind, en, reps in (("tick_1300x900", "tick", 0, 10), ("g3_n16384", "g3", 16384, 5), ("g2_n16384", "g2", 16384, 2)):
+        # g2 twice: the default path (its |a-b| matrix is recognised as a line metric: sorted matching + certificate
+        # pass, td_line.hip) and the general solver alone on the same instance (td_set_line_metric(0))
+        for name, kind, en, reps in (("tick_1300x900", "tick", 0, 10), ("g3_n16384", "g3", 16384, 5), ("g2_n16384", "g2", 16384, 10),
+                                     ("g2_n16384_general_solver", "g2", 16384, 2)):
             try:
+                td.set_line_metric(not name.endswith("general_solver"))
                 w2 = TickWorkload(1, td) if kind == "tick" else Workload(kind, en, 1, torch, td, ffi)
                 w2.step()
                 torch.cuda.synchronize()
@@ -471,6 +482,7 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:
                 extras[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        td.set_line_metric(True)
         line["other_workloads"] = extras
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.workload, n, args.cpu_seconds)

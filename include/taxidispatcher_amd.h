@@ -102,6 +102,14 @@ TD_API int td_cost_build_rows(const int32_t *cab_to, const int32_t *cab_id, int 
  */
 TD_API int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_t *total,
               int64_t *dual_bound);
+/* Line-metric instances.  The reference's distance table is a line (greedy_opt.py:122-127: dist[i][j] = |i - j|),
+ * so its square cost matrices are |a_i - b_j|: sorted by a and b they are Monge and the sorted matching is
+ * optimal.  td_assign tries that matching first (O(n) anchor reads, one sort of 2n keys) and keeps it only
+ * when ONE pass over the matrix proves it optimal on the actual cells (row minima of c[i][j] - v[j] all on
+ * the matched cells; exact 64-bit integers); every other matrix goes to the general solver unchanged.
+ * td_set_line_metric(0) switches the attempt off (1 = on, the default; env TD_LINE=0 does the same);
+ * returns the previous setting. */
+TD_API int td_set_line_metric(int on);
 
 /* n*n bytes of 0/1 in the reference's order i = n*cab + cust (solver.py:36-39) */
 TD_API int td_expand_x(int n, const int32_t *row_to_col, uint8_t *x);
@@ -232,7 +240,9 @@ TD_API int td_memcpy(void *dst, const void *src, uint64_t bytes);
 #define TD_K_SAP 5
 #define TD_K_FINAL 6
 #define TD_K_LCM 7
-#define TD_K_COUNT 8
+#define TD_K_LINE 8   /* line-metric recogniser: anchors, keys, sort, prices */
+#define TD_K_CERT 9   /* ... and its certificate pass over the int32 matrix */
+#define TD_K_COUNT 10
 TD_API int td_profile_enable(int on);                      /* HIP-event timing per kernel class */
 TD_API int td_profile_get(int kernel, double *total_ms, int64_t *launches);
 TD_API int td_profile_reset(void);
@@ -240,7 +250,9 @@ TD_API int td_profile_reset(void);
  * [2]=free rows left to the serial finisher, [3]=its dijkstra steps, [4]=cost storage bytes per cell,
  * [5]=augmentations committed by the parallel finisher, [6]=1 when 4-byte cells were solved with 32-bit prices and labels,
  * [7]=1 when the transposed formulation was solved
- * (many constant columns, see DESIGN.md "rectangular models") */
+ * (many constant columns, see DESIGN.md "rectangular models"),
+ * [8]=1 when the matrix was recognised as a line metric: sorted matching, proven by the certificate pass
+ * (then [0..7] are 0 except [4]=4; see DESIGN.md "line-metric instances") */
 TD_API int td_last_stats(int64_t *out, int n);
 
 #ifdef __cplusplus

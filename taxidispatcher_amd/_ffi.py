@@ -15,7 +15,7 @@ c_i32p = ctypes.c_void_p  # raw addresses: host numpy buffers or device pointers
 _lib = None
 _inited_device = None
 
-TD_K = {"cost_build": 0, "gen": 1, "compress": 2, "bid": 3, "assign": 4, "sap": 5, "final": 6, "lcm": 7}
+TD_K = {"cost_build": 0, "gen": 1, "compress": 2, "bid": 3, "assign": 4, "sap": 5, "final": 6, "lcm": 7, "line": 8, "cert": 9}
 
 # name -> (restype, argtypes) ; must list every TD_API symbol of the header
 SIGNATURES = {
@@ -31,6 +31,7 @@ SIGNATURES = {
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p]),
     "td_assign": (ctypes.c_int, [ctypes.c_int, c_i32p, c_i32p, ctypes.POINTER(ctypes.c_int64),
                                  ctypes.POINTER(ctypes.c_int64)]),
+    "td_set_line_metric": (ctypes.c_int, [ctypes.c_int]),
     "td_expand_x": (ctypes.c_int, [ctypes.c_int, c_i32p, ctypes.c_void_p]),
     "td_lcm": (ctypes.c_int, [ctypes.c_int, c_i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.c_int32,
                               ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_i32p, c_i32p,

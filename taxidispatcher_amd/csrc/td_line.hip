@@ -1,0 +1,499 @@
+// Line-metric recogniser for td_assign.
+//
+// The reference's distance table is a line: greedy_opt.py:122-127 (and simulate.py / procedure.py the
+// same way) fills dist[i][j] = |i - j|, and calculate_cost (greedy_opt.py:86-99) copies
+// dist[cab.to][request.from] into the cost matrix.  A square matrix |a_i - b_j| sorted by a and by b is a
+// Monge matrix: its optimal assignment is the sorted matching, and prices that prove it are a prefix sum
+// of n adjacent differences.  The general solver (td_assign.hip) finds those instances hard when the
+// stands are tie-free, so td_assign tries this first:
+//
+//   1. k_line_probe   one workgroup, O(n) reads: two columns p, q and two rows i1, i2 that lie at different
+//                     positions, and a plausibility test (sampled rows against (p, q), all columns against
+//                     (i1, i2): inside the anchors' span the two distances add up to D, outside they differ by D).
+//                     The host reads the verdict: a matrix that is no line metric costs this kernel and one
+//                     round trip, then the general solver runs.
+//   2. k_line_keys    row key  c[i][p]^2 - c[i][q]^2 = (b_q - b_p)(2 a_i - b_p - b_q): strictly monotone
+//                     in a_i for ANY two distinct columns; columns likewise from rows i1, i2, negated when
+//                     K(i2) < K(i1) says the two orders run in opposite directions;
+//   3. one radix sort of the 2n keys (hipCUB);
+//   4. k_line_gather  row_to_col = the sorted matching, its total, the adjacent differences f[k], and the
+//                     Monge test on the diagonal; k_line_scan: prices v[tau(k+1)] = v[tau(k)] + f[k];
+//   5. k_line_cert    ONE streaming pass over the int32 matrix: for every row, min_j (c[i][j] - v[j]) must be
+//                     attained on the row's matched cell.  Then sum_i c[i][m(i)] = sum_i min_j(..) + sum_j v[j]
+//                     is a lower bound of every assignment: the matching is optimal, whatever the matrix was.
+//
+// Nothing here ASSUMES the structure: the answer is used only when step 5 accepts it on the actual matrix
+// (exact 64-bit arithmetic), otherwise td_assign runs the general solver as before.  Step 5 is the only
+// O(n^2) step and it is HBM-bound: 4 n^2 bytes read once.
+#include <limits.h>
+
+#include <hipcub/hipcub.hpp>
+
+#include "td_common.h"
+
+namespace td {
+namespace {
+
+enum { LC_P = 0, LC_Q, LC_I1, LC_I2, LC_PLAUS, LC_REV, LC_FAIL, LC_FITS32, LC_TOTAL, LC_WORDS };
+
+struct LineWs {
+    Buf ctl, kin, kout, vin, vout, tmp, f, v64, v32, r2c;
+};
+LineWs g_lw;
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+struct ArgMax {
+    long long v;
+    int i;
+};
+__device__ inline bool better(const ArgMax &a, const ArgMax &b) { return a.v > b.v || (a.v == b.v && a.i < b.i); }
+
+// argmax over the block (ties: the smallest index); every thread gets the result
+__device__ ArgMax block_argmax(ArgMax x, ArgMax *sh)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMax y;
+        y.v = __shfl_xor(x.v, o);
+        y.i = __shfl_xor(x.i, o);
+        if (better(y, x)) x = y;
+    }
+    __syncthreads();
+    if (lane == 0) sh[w] = x;
+    __syncthreads();
+    ArgMax r = sh[0];
+    for (int k = 1; k < nw; k++)
+        if (better(sh[k], r)) r = sh[k];
+    return r;
+}
+
+__device__ inline long long labs64(long long x) { return x < 0 ? -x : x; }
+
+// (x, y) = distances of one point to two anchors that are D apart: inside the span x + y == D, outside |x - y| == D
+__device__ inline bool span_ok(long long x, long long y, long long D) { return x + y == D || labs64(x - y) == D; }
+
+// One workgroup, O(n) reads: anchors + a plausibility test, so that a matrix that is no line metric costs one
+// small kernel and one host round trip (the verdict is written straight into the pinned host block).
+//   0. the first 1024 cells of rows 0 and 1 must agree on ONE distance |a_0 - a_1| (inside the two rows' span the
+//      distances add up to it, outside they differ by it): random matrices are refused here after two loads
+//   1. the same over the full rows; q = the column whose distance to row 0 differs most from column 0's
+//      (columns p = 0 and q then lie at different positions; row n/2 is tried when row 0 sees no difference)
+//   2. rows i1 = 0 and i2 = 1 if they lie at different positions, else the sampled row that differs most
+//      (then all columns are tested against (i1, i2) again)
+//   3. the sampled rows against (p, q) must agree on one distance |b_p - b_q|
+//   rev: the column keys must be negated when the two key orders run in opposite directions
+__global__ __launch_bounds__(1024) void k_line_probe(int n, const int32_t *__restrict__ c, long long *__restrict__ ctl,
+                                                     long long *__restrict__ host_verdict)
+{
+    __shared__ ArgMax sh[16];
+    const int t = threadIdx.x, T = blockDim.x;
+    const int p = 0, i1 = 0;
+    const long long u0 = c[0], w0 = c[n];
+    const long long Ea = u0 + w0, Eb = labs64(u0 - w0);
+    int plaus = 0, rev = 0, q = -1, rq = 0, i2 = -1;
+    int bad_a = 0, bad_b = 0;
+    if (t < n) {
+        const long long xx = c[t], yy = c[(size_t)n + t];
+        bad_a = !span_ok(xx, yy, Ea);
+        bad_b = !span_ok(xx, yy, Eb);
+    }
+    bad_a = __syncthreads_or(bad_a);
+    bad_b = __syncthreads_or(bad_b);
+    if (!(bad_a && bad_b)) {
+        ArgMax x;
+        x.v = LLONG_MIN, x.i = 0x7fffffff;
+        bad_a = bad_b = 0;
+        for (int j = t; j < n; j += T) {
+            const long long xx = c[j], yy = c[(size_t)n + j];
+            bad_a |= !span_ok(xx, yy, Ea);
+            bad_b |= !span_ok(xx, yy, Eb);
+            ArgMax y{labs64(xx - u0), j};
+            if (better(y, x)) x = y;
+        }
+        bad_a = __syncthreads_or(bad_a);
+        bad_b = __syncthreads_or(bad_b);
+        ArgMax r = block_argmax(x, sh);
+        if (r.v != 0) q = r.i;
+        bool cols_ok = !(bad_a && bad_b);
+        if (cols_ok && q < 0) {   // row 0 sees every column at one distance: ask row n/2
+            rq = n / 2;
+            const int32_t *row = c + (size_t)rq * n;
+            const long long ref = row[p];
+            x.v = LLONG_MIN, x.i = 0x7fffffff;
+            for (int j = t; j < n; j += T) {
+                ArgMax y{labs64((long long)row[j] - ref), j};
+                if (better(y, x)) x = y;
+            }
+            r = block_argmax(x, sh);
+            if (r.v != 0) q = r.i;
+        }
+        const int step = n > 1024 ? n / 1024 : 1;
+        const int nsamp = (n + step - 1) / step;
+        if (cols_ok && q >= 0) {
+            if (w0 != u0 || c[(size_t)n + q] != c[q])
+                i2 = 1;   // rows 0 and 1 lie at different positions: step 1 was the column test
+            else {
+                for (int attempt = 0; attempt < 2 && i2 < 0; attempt++) {
+                    const int col = attempt == 0 ? p : q;
+                    const long long ref = c[(size_t)i1 * n + col];
+                    x.v = LLONG_MIN, x.i = 0x7fffffff;
+                    for (int k = t; k < nsamp; k += T) {
+                        const int i = k * step;
+                        ArgMax y{labs64((long long)c[(size_t)i * n + col] - ref), i};
+                        if (better(y, x)) x = y;
+                    }
+                    r = block_argmax(x, sh);
+                    if (r.v != 0) i2 = r.i;
+                }
+                if (i2 >= 0) {
+                    const long long uu = c[(size_t)i1 * n + p], ww = c[(size_t)i2 * n + p];
+                    const long long Fa = uu + ww, Fb = labs64(uu - ww);
+                    const int32_t *r1 = c + (size_t)i1 * n, *r2 = c + (size_t)i2 * n;
+                    bad_a = bad_b = 0;
+                    for (int j = t; j < n; j += T) {
+                        const long long xx = r1[j], yy = r2[j];
+                        bad_a |= !span_ok(xx, yy, Fa);
+                        bad_b |= !span_ok(xx, yy, Fb);
+                    }
+                    bad_a = __syncthreads_or(bad_a);
+                    bad_b = __syncthreads_or(bad_b);
+                    cols_ok = !(bad_a && bad_b);
+                }
+            }
+        }
+        if (cols_ok && q >= 0 && i2 >= 0) {
+            const long long x0 = c[(size_t)rq * n + p], y0 = c[(size_t)rq * n + q];
+            const long long Da = x0 + y0, Db = labs64(x0 - y0);
+            bad_a = bad_b = 0;
+            for (int k = t; k < nsamp; k += T) {
+                const int32_t *row = c + (size_t)(k * step) * n;
+                const long long xx = row[p], yy = row[q];
+                bad_a |= !span_ok(xx, yy, Da);
+                bad_b |= !span_ok(xx, yy, Db);
+            }
+            bad_a = __syncthreads_or(bad_a);
+            bad_b = __syncthreads_or(bad_b);
+            plaus = !(bad_a && bad_b);
+            // K(i) = c[i][p]^2 - c[i][q]^2 = (b_q - b_p)(2 a_i - b_p - b_q);  K(i2) - K(i1) has the sign of (b_q - b_p)(a_i2 - a_i1)
+            const long long a1 = c[(size_t)i1 * n + p], b1 = c[(size_t)i1 * n + q], a2 = c[(size_t)i2 * n + p], b2 = c[(size_t)i2 * n + q];
+            rev = (a2 * a2 - b2 * b2) < (a1 * a1 - b1 * b1);
+        }
+    }
+    if (t == 0) {
+        ctl[LC_P] = p;
+        ctl[LC_Q] = q < 0 ? 0 : q;
+        ctl[LC_I1] = i1;
+        ctl[LC_I2] = i2 < 0 ? 0 : i2;
+        ctl[LC_PLAUS] = plaus;
+        ctl[LC_REV] = rev;
+        ctl[LC_FAIL] = !plaus;
+        ctl[LC_FITS32] = 0;
+        ctl[LC_TOTAL] = 0;
+        host_verdict[0] = plaus;
+        __threadfence_system();
+    }
+}
+
+// sort keys: bit 63 = side (0 rows, 1 columns), bits 0..62 = key + 2^62 (|key| < 2^62 for int32 cells)
+__global__ __launch_bounds__(256) void k_line_keys(int n, const int32_t *__restrict__ c, const long long *__restrict__ ctl,
+                                                   unsigned long long *__restrict__ keys, int *__restrict__ vals)
+{
+    const int p = (int)ctl[LC_P], q = (int)ctl[LC_Q], i1 = (int)ctl[LC_I1], i2 = (int)ctl[LC_I2];
+    const bool rev = ctl[LC_REV] != 0;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < 2 * n; t += gridDim.x * blockDim.x) {
+        long long x, y;
+        if (t < n) {
+            x = c[(size_t)t * n + p];
+            y = c[(size_t)t * n + q];
+        } else {
+            x = c[(size_t)i1 * n + (t - n)];
+            y = c[(size_t)i2 * n + (t - n)];
+        }
+        long long key = x * x - y * y;
+        if (t >= n && rev) key = -key;
+        keys[t] = (unsigned long long)(key + (1ll << 62)) | (t < n ? 0ull : 1ull << 63);
+        vals[t] = t < n ? t : t - n;
+    }
+}
+
+// sorted[0..n) = rows by key (s), sorted[n..2n) = columns by key (tau): row_to_col, the adjacent differences
+//   f[k] = c[s(k)][tau(k+1)] - c[s(k)][tau(k)]   (price step)      b[k] = c[s(k+1)][tau(k)] - c[s(k+1)][tau(k+1)]
+// (f + b < 0 is a Monge violation on the diagonal: no prices can make both matched cells row minima), and the total.
+__global__ __launch_bounds__(256) void k_line_gather(int n, const int32_t *__restrict__ c, const int *__restrict__ sorted,
+                                                     long long *__restrict__ ctl, long long *__restrict__ f, int *__restrict__ r2c)
+{
+    __shared__ long long sh[4];
+    const int *sig = sorted, *tau = sorted + n;
+    long long sum = 0;
+    int bad = 0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const int s = sig[k], tk = tau[k];
+        const int32_t *row = c + (size_t)s * n;
+        const long long ckk = row[tk];
+        long long d = 0;
+        if (k + 1 < n) {
+            const int tk1 = tau[k + 1];
+            const int32_t *row1 = c + (size_t)sig[k + 1] * n;
+            d = (long long)row[tk1] - ckk;
+            const long long b = (long long)row1[tk] - (long long)row1[tk1];
+            bad |= d + b < 0;
+        }
+        f[k] = d;
+        r2c[s] = tk;
+        sum += ckk;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sum = sh[0] + sh[1] + sh[2] + sh[3];
+        if (sum) atomicAdd((unsigned long long *)&ctl[LC_TOTAL], (unsigned long long)sum);
+    }
+    if (bad) ctl[LC_FAIL] = 1;
+}
+
+// one workgroup: prices = exclusive prefix sums of f along the sorted columns (CH tiles of 1024 loaded up front,
+// so the serial chain of tile scans does not wait on memory)
+__global__ __launch_bounds__(1024) void k_line_scan(int n, const int *__restrict__ sorted, long long *__restrict__ ctl,
+                                                    const long long *__restrict__ f, long long *__restrict__ v64,
+                                                    int32_t *__restrict__ v32)
+{
+    constexpr int CH = 16;
+    __shared__ long long wsum[2][16];
+    __shared__ int wide;
+    const int t = threadIdx.x, T = blockDim.x, lane = t & 63, w = t >> 6, nw = T >> 6;
+    const int *tau = sorted + n;
+    if (t == 0) wide = 0;
+    long long carry = 0;
+    bool out = false;
+    int par = 0;
+    for (int base = 0; base < n; base += T * CH) {
+        long long x[CH];
+        int col[CH];
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+            const int k = base + u * T + t;
+            x[u] = k < n ? f[k] : 0;
+            col[u] = k < n ? tau[k] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+            if (base + u * T >= n) break;
+            long long inc = x[u];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const long long y = __shfl_up(inc, o);
+                if (lane >= o) inc += y;
+            }
+            if (lane == 63) wsum[par][w] = inc;
+            __syncthreads();   // (the other wsum buffer is written next: one barrier per tile)
+            long long before = carry, all = 0;
+            for (int j = 0; j < nw; j++) {
+                const long long ws = wsum[par][j];
+                if (j < w) before += ws;
+                all += ws;
+            }
+            par ^= 1;
+            const long long price = before + inc - x[u];   // exclusive
+            if (col[u] >= 0) {
+                v64[col[u]] = price;
+                v32[col[u]] = (int32_t)price;
+                out |= price < -(1ll << 30) || price > (1ll << 30);
+            }
+            carry += all;
+        }
+    }
+    if (out) wide = 1;
+    __syncthreads();
+    if (t == 0) ctl[LC_FITS32] = !wide;
+}
+
+// The certificate: row i passes when no cell of the row beats its matched cell, min_j (c[i][j] - v[j]) == c[i][m] - v[m].
+// R rows per workgroup sweep so a price vector chunk is loaded once per R cost chunks; 16-byte loads.
+template <typename VT, int R, bool VEC>
+__device__ void line_cert_body(int n, const int32_t *__restrict__ c, const VT *__restrict__ v, const int *__restrict__ r2c,
+                               long long *__restrict__ ctl, long long *sh)
+{
+    const int t = threadIdx.x, T = blockDim.x, lane = t & 63, w = t >> 6, nw = T >> 6;
+    const int ngroups = (n + R - 1) / R;
+    for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const int r0 = g * R;
+        long long m[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) m[r] = LLONG_MAX;
+        if (VEC) {
+            const int nq = n >> 2;
+            for (int ch = t; ch < nq; ch += T) {
+                long long pv[4];
+                if (sizeof(VT) == 4) {
+                    const int4 x = *reinterpret_cast<const int4 *>((const int32_t *)v + 4 * (size_t)ch);
+                    pv[0] = x.x, pv[1] = x.y, pv[2] = x.z, pv[3] = x.w;
+                } else {
+                    const longlong2 x = *reinterpret_cast<const longlong2 *>((const long long *)v + 4 * (size_t)ch);
+                    const longlong2 y = *reinterpret_cast<const longlong2 *>((const long long *)v + 4 * (size_t)ch + 2);
+                    pv[0] = x.x, pv[1] = x.y, pv[2] = y.x, pv[3] = y.y;
+                }
+                v4i cv[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int row = std::min(r0 + r, n - 1);
+                    cv[r] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(c + (size_t)row * n) + ch);
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    long long a = (long long)cv[r].x - pv[0], b = (long long)cv[r].y - pv[1];
+                    long long d = (long long)cv[r].z - pv[2], e = (long long)cv[r].w - pv[3];
+                    a = a < b ? a : b;
+                    d = d < e ? d : e;
+                    a = a < d ? a : d;
+                    m[r] = a < m[r] ? a : m[r];
+                }
+            }
+        } else {
+            for (int j = t; j < n; j += T) {
+                const long long pv = (long long)v[j];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int row = std::min(r0 + r, n - 1);
+                    const long long a = (long long)c[(size_t)row * n + j] - pv;
+                    m[r] = a < m[r] ? a : m[r];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const long long y = __shfl_xor(m[r], o);
+                m[r] = y < m[r] ? y : m[r];
+            }
+        }
+        __syncthreads();
+        if (lane == 0)
+            for (int r = 0; r < R; r++) sh[r * 16 + w] = m[r];
+        __syncthreads();
+        if (t < R && r0 + t < n) {
+            long long mm = sh[t * 16];
+            for (int k = 1; k < nw; k++) mm = sh[t * 16 + k] < mm ? sh[t * 16 + k] : mm;
+            const int row = r0 + t, col = r2c[row];
+            const long long tight = (long long)c[(size_t)row * n + col] - (long long)v[col];
+            if (mm != tight) ctl[LC_FAIL] = 1;
+        }
+    }
+}
+
+template <int R, bool VEC>
+__global__ __launch_bounds__(256) void k_line_cert(int n, const int32_t *__restrict__ c, const long long *__restrict__ v64,
+                                                   const int32_t *__restrict__ v32, const int *__restrict__ r2c,
+                                                   long long *__restrict__ ctl)
+{
+    __shared__ long long sh[R * 16];
+    if (ctl[LC_FAIL]) return;   // the gather pass already found a violation
+    if (ctl[LC_FITS32])
+        line_cert_body<int32_t, R, VEC>(n, c, v32, r2c, ctl, sh);
+    else
+        line_cert_body<long long, R, VEC>(n, c, v64, r2c, ctl, sh);
+}
+
+}  // namespace
+
+constexpr size_t VERDICT_OFF = 4096;   // byte offset of the probe's verdict in the pinned host block (clear of the other read-backs)
+hipEvent_t g_probe_done = nullptr;
+
+int line_probe_launch(int n, const int32_t *d_cost, const long long **skip_dev)
+{
+    Ctx &c = ctx();
+    int rc;
+    if ((rc = ensure(g_lw.ctl, 256))) return rc;
+    if (!g_probe_done) TD_HIP(hipEventCreateWithFlags(&g_probe_done, hipEventDisableTiming));
+    long long *ctl = (long long *)g_lw.ctl.p;
+    {
+        ProfScope ps(TD_K_LINE);
+        k_line_probe<<<1, 1024, 0, c.stream>>>(n, d_cost, ctl, (long long *)((char *)c.pinned + VERDICT_OFF));
+        TD_HIP(hipGetLastError());
+    }
+    TD_HIP(hipEventRecord(g_probe_done, c.stream));
+    *skip_dev = ctl + LC_PLAUS;
+    return TD_OK;
+}
+
+int line_probe_wait(int *plausible)
+{
+    Ctx &c = ctx();
+    TD_HIP(hipEventSynchronize(g_probe_done));
+    *plausible = *(volatile const long long *)((char *)c.pinned + VERDICT_OFF) != 0;
+    return TD_OK;
+}
+
+// The sorted matching on the n x n device matrix (after a "plausible" probe). *accepted = 1: *r2c_dev points at the
+// library's device copy of row_to_col and *total is its cost, proven optimal by the certificate pass.
+int line_finish(int n, const int32_t *d_cost, const int32_t **r2c_dev, int64_t *total, int *accepted)
+{
+    Ctx &c = ctx();
+    *accepted = 0;
+    int rc;
+    const size_t np = (size_t)n + 16;
+    if ((rc = ensure(g_lw.kin, 16 * np))) return rc;
+    if ((rc = ensure(g_lw.kout, 16 * np))) return rc;
+    if ((rc = ensure(g_lw.vin, 8 * np))) return rc;
+    if ((rc = ensure(g_lw.vout, 8 * np))) return rc;
+    if ((rc = ensure(g_lw.f, 8 * np))) return rc;
+    if ((rc = ensure(g_lw.v64, 8 * np))) return rc;
+    if ((rc = ensure(g_lw.v32, 4 * np))) return rc;
+    if ((rc = ensure(g_lw.r2c, 4 * np))) return rc;
+    long long *ctl = (long long *)g_lw.ctl.p;
+    auto *kin = (unsigned long long *)g_lw.kin.p, *kout = (unsigned long long *)g_lw.kout.p;
+    int *vin = (int *)g_lw.vin.p, *vout = (int *)g_lw.vout.p;
+    {
+        ProfScope ps(TD_K_LINE);
+        k_line_keys<<<std::max(1, std::min(c.n_cu * 4, (2 * n + 255) / 256)), 256, 0, c.stream>>>(n, d_cost, ctl, kin, vin);
+        size_t bytes = 0;
+        TD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin, kout, vin, vout, 2 * n, 0, 64, c.stream));
+        if ((rc = ensure(g_lw.tmp, bytes + 256))) return rc;
+        TD_HIP(hipcub::DeviceRadixSort::SortPairs(g_lw.tmp.p, bytes, kin, kout, vin, vout, 2 * n, 0, 64, c.stream));
+        k_line_gather<<<std::max(1, std::min(c.n_cu * 4, (n + 255) / 256)), 256, 0, c.stream>>>(n, d_cost, vout, ctl, (long long *)g_lw.f.p,
+                                                                                            (int *)g_lw.r2c.p);
+        k_line_scan<<<1, 1024, 0, c.stream>>>(n, vout, ctl, (const long long *)g_lw.f.p, (long long *)g_lw.v64.p, (int32_t *)g_lw.v32.p);
+        TD_HIP(hipGetLastError());
+    }
+    {
+        ProfScope ps(TD_K_CERT);
+        constexpr int R = 4;
+        const int ngroups = (n + R - 1) / R;
+        const int grid = std::max(1, std::min(ngroups, c.n_cu * 16));
+        const bool vec = (n % 4 == 0) && (((uintptr_t)d_cost & 15) == 0);
+        if (vec)
+            k_line_cert<R, true><<<grid, 256, 0, c.stream>>>(n, d_cost, (const long long *)g_lw.v64.p, (const int32_t *)g_lw.v32.p,
+                                                             (const int *)g_lw.r2c.p, ctl);
+        else
+            k_line_cert<R, false><<<grid, 256, 0, c.stream>>>(n, d_cost, (const long long *)g_lw.v64.p, (const int32_t *)g_lw.v32.p,
+                                                              (const int *)g_lw.r2c.p, ctl);
+        TD_HIP(hipGetLastError());
+    }
+    TD_HIP(hipMemcpyAsync(c.pinned, ctl, LC_WORDS * sizeof(long long), hipMemcpyDeviceToHost, c.stream));
+    TD_HIP(hipStreamSynchronize(c.stream));
+    const long long *h = (const long long *)c.pinned;
+    if (h[LC_FAIL] == 0) {
+        *accepted = 1;
+        *total = h[LC_TOTAL];
+        *r2c_dev = (const int32_t *)g_lw.r2c.p;
+    }
+    return TD_OK;
+}
+
+void line_release_workspace()
+{
+    if (g_probe_done) (void)hipEventDestroy(g_probe_done);
+    g_probe_done = nullptr;
+    Buf *bs[] = {&g_lw.ctl, &g_lw.kin, &g_lw.kout, &g_lw.vin, &g_lw.vout, &g_lw.tmp, &g_lw.f, &g_lw.v64, &g_lw.v32, &g_lw.r2c};
+    for (Buf *b : bs) {
+        if (b->p) (void)hipFree(b->p);
+        b->p = nullptr;
+        b->cap = 0;
+    }
+}
+
+}  // namespace td

@@ -108,6 +108,12 @@ def assign(cost, n=None, want_dual=False):
     return r2c, int(total.value)
 
 
+def set_line_metric(on):
+    """Switch td_assign's line-metric attempt (sorted matching + certificate pass, td_line.hip) on or off;
+    returns the previous setting. On by default."""
+    return bool(_ffi.lib().td_set_line_metric(1 if on else 0))
+
+
 def expand_x(n, row_to_col):
     """row_to_col -> the reference's n*n 0/1 vector, index n*cab + cust (solver.py:36-39)."""
     x = np.zeros(n * n, np.uint8)
@@ -120,7 +126,7 @@ def last_stats():
     out = (ctypes.c_int64 * 16)()
     _ffi.check(_ffi.lib().td_last_stats(out, 16))
     d = {"bid_rounds": out[0], "warm_rounds": out[1], "sap_free_rows": out[2], "sap_steps": out[3], "bytes_per_cell": out[4],
-         "parallel_sap_rows": out[5], "narrow_price": out[6], "transposed": out[7]}
+         "parallel_sap_rows": out[5], "narrow_price": out[6], "transposed": out[7], "line_metric": out[8]}
     return d
 
 

@@ -19,3 +19,11 @@ def td():
     td_mod.init(0)
     yield td_mod
     td_mod.shutdown()
+
+
+@pytest.fixture()
+def general_solver(td):
+    """td_assign with the line-metric attempt (td_line.hip) switched off: the general solver alone."""
+    was = td.set_line_metric(False)
+    yield td
+    td.set_line_metric(was)

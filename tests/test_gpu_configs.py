@@ -18,6 +18,13 @@ BIG = 250000
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True)
+def _general_solver_only(general_solver):
+    """This module pins the GENERAL solver: |a-b| instances would otherwise be answered by the line-metric
+    attempt (sorted matching + certificate, tests/test_gpu_line.py) before the solver under test runs."""
+    yield
+
+
 def test_config0_20x20_procedure_api(td):
     """BASELINE configs[0] / SURVEY G0: 20 cabs x 20 requests through procedure.py's call shape
     (procedure.py:5-29): dist = |i - j| on S = 50 stands, ids 0..19, cells addressed by id, fill n*n."""
@@ -107,12 +114,16 @@ def test_cost_build_rows_window(td):
                                   _ffi.addr(blk)) == -1   # window outside the model: TD_EINVAL
 
 
-@pytest.mark.parametrize("kind", ["g2", "g3"])
+@pytest.mark.parametrize("kind", ["g2", "g2-line", "g3"])
 def test_headline_size_other_families(td, kind):
     """SURVEY 8d lists G2 (|a-b|, greedy_opt.py's own cost model) and G3 (simulator-like) for the
-    headline size N = 16 384: exact total with the device certificate; G2 also against the closed form."""
+    headline size N = 16 384: exact total with the device certificate; G2 also against the closed form,
+    by the general solver ("g2") and by the default path with the line-metric attempt on ("g2-line")."""
     import torch
     n = 16384
+    if kind == "g2-line":
+        td.set_line_metric(True)    # the module fixture restores the setting
+        kind = "g2"
     rng = np.random.default_rng(1)
     ct = torch.empty((n, n), dtype=torch.int32, device="cuda")
     if kind == "g2":

@@ -15,6 +15,13 @@ GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "known_a
 BIG = 250000
 
 
+@pytest.fixture(autouse=True)
+def _general_solver_only(general_solver):
+    """This module pins the GENERAL solver: |a-b| instances would otherwise be answered by the line-metric
+    attempt (sorted matching + certificate, tests/test_gpu_line.py) before the solver under test runs."""
+    yield
+
+
 def make_instance(kind, n, rng):
     if kind == "g1":      # perf.jl:5
         return rng.integers(10, 41, (n, n)).astype(np.int32)
