@@ -252,7 +252,8 @@ TD_API int td_profile_reset(void);
  * [7]=1 when the transposed formulation was solved
  * (many constant columns, see DESIGN.md "rectangular models"),
  * [8]=1 when the matrix was recognised as a line metric: sorted matching, proven by the certificate pass
- * (then [0..7] are 0 except [4]=4; see DESIGN.md "line-metric instances") */
+ * (then [0..6] are 0 except [4]=4, [7]=1 when it was the transpose that was recognised (constant trailing columns),
+ * [9] = number of constant rows of the unbalanced model; see DESIGN.md "line-metric instances") */
 TD_API int td_last_stats(int64_t *out, int n);
 
 #ifdef __cplusplus

@@ -3069,6 +3069,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     // front of the first compress pass and its verdict is awaited while that pass runs, so a refusal costs
     // the probe kernel alone; when the probe says "plausible" the compress pass returns at once (sv.skip).
     bool line_pending = false;
+    c.stats[8] = c.stats[9] = 0;
     if (g_line && n >= g_line_min_n && !g_solver_eps) {
         if ((rc = line_probe_launch(n, sv.d_cost, &sv.skip))) return rc;
         line_pending = true;
@@ -3097,15 +3098,36 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         if (line_pending) {
             line_pending = false;
             sv.skip = nullptr;
-            int plausible = 0, accepted = 0;
-            if ((rc = line_probe_wait(&plausible))) return rc;
-            if (plausible) {
+            int mode = 0, kd = 0, accepted = 0;
+            if ((rc = line_probe_wait(&mode, &kd))) return rc;
+            if (mode) {
                 const int32_t *res = nullptr;
-                if ((rc = line_finish(n, sv.d_cost, &res, &tot, &accepted))) return rc;
+                bool line_t = false;
+                if (mode == 2) {
+                    // constant trailing COLUMNS (more cabs than requests): the same model on the transpose
+                    if ((rc = ensure(sv.tbuf, sizeof(int32_t) * (size_t)n * n))) return rc;
+                    k_transpose<<<dim3((n + 63) / 64, (n + 63) / 64), 256, 0, c.stream>>>(n, sv.d_cost, (int32_t *)sv.tbuf.p);
+                    TD_HIP(hipGetLastError());
+                    const long long *unused = nullptr;
+                    if ((rc = line_probe_launch(n, (const int32_t *)sv.tbuf.p, &unused))) return rc;
+                    if ((rc = line_probe_wait(&mode, &kd))) return rc;
+                    line_t = true;
+                }
+                if (mode == 1 || mode == 3) {
+                    if ((rc = line_finish(n, mode == 3 ? kd : 0, line_t ? (const int32_t *)sv.tbuf.p : sv.d_cost, &res, &tot, &accepted)))
+                        return rc;
+                }
                 if (accepted) {
                     for (int k = 0; k < 16; k++) c.stats[k] = 0;
                     c.stats[4] = 4;
+                    c.stats[7] = line_t ? 1 : 0;
                     c.stats[8] = 1;
+                    c.stats[9] = mode == 3 ? kd : 0;
+                    if (line_t) {   // res[column] = row of the caller's matrix: invert
+                        k_r2c_from_owner<<<(n + 255) / 256, 256, 0, c.stream>>>(n, n, 0, (const int *)res, (int *)sv.r2c.p);
+                        TD_HIP(hipGetLastError());
+                        res = (const int32_t *)sv.r2c.p;
+                    }
                     TD_HIP(hipMemcpyAsync(row_to_col, res, sizeof(int32_t) * (size_t)n,
                                           is_device_ptr(row_to_col) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c.stream));
                     TD_HIP(hipStreamSynchronize(c.stream));

@@ -52,12 +52,14 @@ bool is_device_ptr(const void *p);
 // returns a device pointer holding `bytes` of src (src itself when already on the device)
 int to_device(const void *src, size_t bytes, Buf &stage, const void **out);
 // td_line.hip: sorted matching + certificate pass for line-metric matrices (tried first by td_assign)
-//   line_probe_launch  queues the O(n) probe; *skip_dev = device word that is non-zero when the probe says "plausible"
-//   line_probe_wait    waits for the probe alone (an event, not the stream) and returns its verdict
+//   line_probe_launch  queues the O(n) probe; *skip_dev = device word that is non-zero unless the probe refuses
+//   line_probe_wait    waits for the probe alone (an event, not the stream) and returns its verdict:
+//                      0 refused, 1 plausible, 2 constant trailing columns (retry on the transpose),
+//                      3 plausible with *k constant rows (the unbalanced model)
 //   line_finish        keys, sort, prices, certificate pass; *accepted = 1: *r2c_dev / *total are proven optimal
 int line_probe_launch(int n, const int32_t *d_cost, const long long **skip_dev);
-int line_probe_wait(int *plausible);
-int line_finish(int n, const int32_t *d_cost, const int32_t **r2c_dev, int64_t *total, int *accepted);
+int line_probe_wait(int *mode, int *k);
+int line_finish(int n, int k, const int32_t *d_cost, const int32_t **r2c_dev, int64_t *total, int *accepted);
 void line_release_workspace();
 void prof_begin(int k);
 void prof_end(int k);

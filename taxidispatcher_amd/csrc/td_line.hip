@@ -34,10 +34,14 @@
 namespace td {
 namespace {
 
-enum { LC_P = 0, LC_Q, LC_I1, LC_I2, LC_PLAUS, LC_REV, LC_FAIL, LC_FITS32, LC_TOTAL, LC_WORDS };
+// LC_PLAUS: 0 refused; 1 balanced line metric plausible; 2 constant trailing COLUMNS (retry on the transpose);
+//           3 plausible with LC_K constant rows (the unbalanced model: fewer cabs than requests)
+enum { LC_P = 0, LC_Q, LC_I1, LC_I2, LC_PLAUS, LC_REV, LC_FAIL, LC_FITS32, LC_TOTAL, LC_K, LC_FILL, LC_WORDS };
+constexpr int LINE_KMAX = 8;   // most constant rows the unbalanced plan is made for
 
 struct LineWs {
     Buf ctl, kin, kout, vin, vout, tmp, f, v64, v32, r2c;
+    Buf band, P, E, ARG, Bk, L, mcol;   // the unbalanced plan (k_line_unbal)
 };
 LineWs g_lw;
 
@@ -77,31 +81,45 @@ __device__ inline bool span_ok(long long x, long long y, long long D) { return x
 // One workgroup, O(n) reads: anchors + a plausibility test, so that a matrix that is no line metric costs one
 // small kernel and one host round trip (the verdict is written straight into the pinned host block).
 //   0. the first 1024 cells of rows 0 and 1 must agree on ONE distance |a_0 - a_1| (inside the two rows' span the
-//      distances add up to it, outside they differ by it): random matrices are refused here after two loads
+//      distances add up to it, outside they differ by it): random matrices are refused here after two loads.
+//      In the same round trip: is the last COLUMN constant over the sampled rows (model padded with dummy
+//      requests: verdict 2, the host retries on the transpose), is the last ROW constant (dummy cabs)?
 //   1. the same over the full rows; q = the column whose distance to row 0 differs most from column 0's
 //      (columns p = 0 and q then lie at different positions; row n/2 is tried when row 0 sees no difference)
 //   2. rows i1 = 0 and i2 = 1 if they lie at different positions, else the sampled row that differs most
 //      (then all columns are tested against (i1, i2) again)
-//   3. the sampled rows against (p, q) must agree on one distance |b_p - b_q|
+//   3. the sampled rows against (p, q) must agree on one distance |b_p - b_q|; constant rows are skipped and
+//      counted (k of them: verdict 3 when 1 <= k <= LINE_KMAX)
 //   rev: the column keys must be negated when the two key orders run in opposite directions
 __global__ __launch_bounds__(1024) void k_line_probe(int n, const int32_t *__restrict__ c, long long *__restrict__ ctl,
                                                      long long *__restrict__ host_verdict)
 {
     __shared__ ArgMax sh[16];
+    __shared__ int s_cnt;
     const int t = threadIdx.x, T = blockDim.x;
     const int p = 0, i1 = 0;
+    const int step = n > 1024 ? n / 1024 : 1;
+    const int nsamp = (n + step - 1) / step;
     const long long u0 = c[0], w0 = c[n];
     const long long Ea = u0 + w0, Eb = labs64(u0 - w0);
-    int plaus = 0, rev = 0, q = -1, rq = 0, i2 = -1;
-    int bad_a = 0, bad_b = 0;
+    const long long B0 = c[(size_t)(n - 1) * n], B1 = c[n - 1];
+    int mode = 0, rev = 0, q = -1, rq = 0, i2 = -1, kdummy = 0;
+    int bad_a = 0, bad_b = 0, rowvar = 0, colvar = 0;
+    if (t == 0) s_cnt = 0;
     if (t < n) {
         const long long xx = c[t], yy = c[(size_t)n + t];
         bad_a = !span_ok(xx, yy, Ea);
         bad_b = !span_ok(xx, yy, Eb);
+        rowvar = c[(size_t)(n - 1) * n + t] != B0;
     }
+    if (t < nsamp) colvar = c[(size_t)(t * step) * n + (n - 1)] != B1;
     bad_a = __syncthreads_or(bad_a);
     bad_b = __syncthreads_or(bad_b);
-    if (!(bad_a && bad_b)) {
+    const bool rows_dummy = !__syncthreads_or(rowvar);
+    const bool cols_dummy = !__syncthreads_or(colvar);
+    if (cols_dummy) {
+        mode = rows_dummy ? 0 : 2;
+    } else if (!(bad_a && bad_b)) {
         ArgMax x;
         x.v = LLONG_MIN, x.i = 0x7fffffff;
         bad_a = bad_b = 0;
@@ -117,8 +135,8 @@ __global__ __launch_bounds__(1024) void k_line_probe(int n, const int32_t *__res
         ArgMax r = block_argmax(x, sh);
         if (r.v != 0) q = r.i;
         bool cols_ok = !(bad_a && bad_b);
-        if (cols_ok && q < 0) {   // row 0 sees every column at one distance: ask row n/2
-            rq = n / 2;
+        if (cols_ok && q < 0) {   // row 0 sees every column at one distance: ask row n/2 (a real row: dummies are at the end)
+            rq = rows_dummy ? 1 : n / 2;
             const int32_t *row = c + (size_t)rq * n;
             const long long ref = row[p];
             x.v = LLONG_MIN, x.i = 0x7fffffff;
@@ -129,8 +147,6 @@ __global__ __launch_bounds__(1024) void k_line_probe(int n, const int32_t *__res
             r = block_argmax(x, sh);
             if (r.v != 0) q = r.i;
         }
-        const int step = n > 1024 ? n / 1024 : 1;
-        const int nsamp = (n + step - 1) / step;
         if (cols_ok && q >= 0) {
             if (w0 != u0 || c[(size_t)n + q] != c[q])
                 i2 = 1;   // rows 0 and 1 lie at different positions: step 1 was the column test
@@ -141,7 +157,8 @@ __global__ __launch_bounds__(1024) void k_line_probe(int n, const int32_t *__res
                     x.v = LLONG_MIN, x.i = 0x7fffffff;
                     for (int k = t; k < nsamp; k += T) {
                         const int i = k * step;
-                        ArgMax y{labs64((long long)c[(size_t)i * n + col] - ref), i};
+                        const bool dummy = rows_dummy && c[(size_t)i * n + p] == B0 && c[(size_t)i * n + q] == B0;
+                        ArgMax y{dummy ? 0ll : labs64((long long)c[(size_t)i * n + col] - ref), i};
                         if (better(y, x)) x = y;
                     }
                     r = block_argmax(x, sh);
@@ -170,12 +187,23 @@ __global__ __launch_bounds__(1024) void k_line_probe(int n, const int32_t *__res
             for (int k = t; k < nsamp; k += T) {
                 const int32_t *row = c + (size_t)(k * step) * n;
                 const long long xx = row[p], yy = row[q];
+                if (rows_dummy && xx == B0 && yy == B0) continue;
                 bad_a |= !span_ok(xx, yy, Da);
                 bad_b |= !span_ok(xx, yy, Db);
             }
             bad_a = __syncthreads_or(bad_a);
             bad_b = __syncthreads_or(bad_b);
-            plaus = !(bad_a && bad_b);
+            mode = !(bad_a && bad_b);
+            if (mode && rows_dummy) {   // count the constant rows (anywhere, they are sorted to the end by their key)
+                int cnt = 0;
+                for (int i = t; i < n; i += T) cnt += c[(size_t)i * n + p] == B0 && c[(size_t)i * n + q] == B0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+                if ((t & 63) == 0 && cnt) atomicAdd(&s_cnt, cnt);
+                __syncthreads();
+                kdummy = s_cnt;
+                mode = (kdummy >= 1 && kdummy <= LINE_KMAX && n - kdummy >= 2) ? 3 : 0;
+            }
             // K(i) = c[i][p]^2 - c[i][q]^2 = (b_q - b_p)(2 a_i - b_p - b_q);  K(i2) - K(i1) has the sign of (b_q - b_p)(a_i2 - a_i1)
             const long long a1 = c[(size_t)i1 * n + p], b1 = c[(size_t)i1 * n + q], a2 = c[(size_t)i2 * n + p], b2 = c[(size_t)i2 * n + q];
             rev = (a2 * a2 - b2 * b2) < (a1 * a1 - b1 * b1);
@@ -186,12 +214,15 @@ __global__ __launch_bounds__(1024) void k_line_probe(int n, const int32_t *__res
         ctl[LC_Q] = q < 0 ? 0 : q;
         ctl[LC_I1] = i1;
         ctl[LC_I2] = i2 < 0 ? 0 : i2;
-        ctl[LC_PLAUS] = plaus;
+        ctl[LC_PLAUS] = mode;
         ctl[LC_REV] = rev;
-        ctl[LC_FAIL] = !plaus;
+        ctl[LC_FAIL] = mode == 0;
         ctl[LC_FITS32] = 0;
         ctl[LC_TOTAL] = 0;
-        host_verdict[0] = plaus;
+        ctl[LC_K] = kdummy;
+        ctl[LC_FILL] = B0;
+        host_verdict[0] = mode;
+        host_verdict[1] = kdummy;
         __threadfence_system();
     }
 }
@@ -202,11 +233,18 @@ __global__ __launch_bounds__(256) void k_line_keys(int n, const int32_t *__restr
 {
     const int p = (int)ctl[LC_P], q = (int)ctl[LC_Q], i1 = (int)ctl[LC_I1], i2 = (int)ctl[LC_I2];
     const bool rev = ctl[LC_REV] != 0;
+    const bool unbal = ctl[LC_PLAUS] == 3;
+    const long long fill = ctl[LC_FILL];
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < 2 * n; t += gridDim.x * blockDim.x) {
         long long x, y;
         if (t < n) {
             x = c[(size_t)t * n + p];
             y = c[(size_t)t * n + q];
+            if (unbal && x == fill && y == fill) {   // a constant row: behind every real row
+                keys[t] = 0x7fffffffffffffffull;
+                vals[t] = t;
+                continue;
+            }
         } else {
             x = c[(size_t)i1 * n + (t - n)];
             y = c[(size_t)i2 * n + (t - n)];
@@ -309,6 +347,205 @@ __global__ __launch_bounds__(1024) void k_line_scan(int n, const int *__restrict
     if (out) wide = 1;
     __syncthreads();
     if (t == 0) ctl[LC_FITS32] = !wide;
+}
+
+// -------------------------------------------------------------------------------------
+// The unbalanced model (greedy_opt.py:88-90: n = max(cabs, requests), the missing cabs are rows of big_cost):
+// m real rows, n = m + k columns, k constant rows.  The real rows take m of the n columns in sorted order
+// (an optimal matching of points on a line does not cross), i.e. row i of the sorted order takes sorted column
+// i + shift(i) with a non-decreasing shift in 0..k.  With P_d[t] = sum_{i<t} c[s(i)][tau(i+d)]:
+//     E_0[t] = P_0[t],   E_d[t] = P_d[t] + min_{t' <= t} (E_{d-1}[t'] - P_d[t'])        (rows < t' keep a shift < d)
+// is k prefix-min scans; the optimum is E_k[m] and the argmins give the rows t_1 <= ... <= t_k where the shift
+// steps up.  Step d skips sorted column t_d + d - 1: those k columns go to the constant rows at price 0, the
+// matched columns get  v = min(L, R) <= 0,  L_i = min(0, L_{i-1} + f_{i-1}),  R_i = min(0, R_{i+1} + b_i)
+// (the cheapest alternating walk that ends in the column, walks may start anywhere because a skipped column
+// reaches every column at no cost).  As in the balanced case nothing is taken on trust: k_line_cert checks
+// the n rows of the actual matrix against these prices.
+// -------------------------------------------------------------------------------------
+struct P2 {
+    long long a, b;
+};
+struct OpSum {   // a = running sum
+    static __device__ P2 id() { return {0, 0}; }
+    static __device__ P2 f(P2 x, P2 y) { return {x.a + y.a, 0}; }
+};
+struct OpMinArg {   // a = value, b = index; the EARLIER element wins a tie
+    static __device__ P2 id() { return {LLONG_MAX, 0}; }
+    static __device__ P2 f(P2 x, P2 y) { return y.a < x.a ? y : x; }
+};
+struct OpClamp {   // the map z -> min(a, z + b); f(x, y) = "x, then y"
+    static __device__ P2 id() { return {LLONG_MAX / 4, 0}; }
+    static __device__ P2 f(P2 x, P2 y) { return {y.a < x.a + y.b ? y.a : x.a + y.b, x.b + y.b}; }
+};
+
+// inclusive scan by ONE workgroup of 1024 threads over `len` elements (load(idx) -> store(idx, prefix)), front to
+// back or back to front; CH tiles are loaded before the serial chain of tile scans starts
+template <typename Op, typename Load, typename Store>
+__device__ void wg_scan(int len, bool reverse, Load load, Store store, P2 *wsum)
+{
+    constexpr int CH = 8;
+    const int t = threadIdx.x, T = blockDim.x, lane = t & 63, w = t >> 6, nw = T >> 6;
+    P2 carry = Op::id();
+    int par = 0;
+    for (int base = 0; base < len; base += T * CH) {
+        P2 x[CH];
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+            const int pos = base + u * T + t;
+            x[u] = pos < len ? load(reverse ? len - 1 - pos : pos) : Op::id();
+        }
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+            if (base + u * T >= len) break;
+            P2 inc = x[u];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                P2 y;
+                y.a = __shfl_up(inc.a, o);
+                y.b = __shfl_up(inc.b, o);
+                if (lane >= o) inc = Op::f(y, inc);
+            }
+            if (lane == 63) wsum[par * 16 + w] = inc;
+            __syncthreads();
+            P2 before = carry, tot = carry;
+            for (int j = 0; j < nw; j++) {
+                const P2 ws = wsum[par * 16 + j];
+                if (j < w) before = Op::f(before, ws);
+                tot = Op::f(tot, ws);
+            }
+            par ^= 1;
+            const int pos = base + u * T + t;
+            if (pos < len) store(reverse ? len - 1 - pos : pos, Op::f(before, inc));
+            carry = tot;
+        }
+    }
+    __syncthreads();
+}
+
+// band[d][i] = c[s(i)][tau(i + d)], i < m, d <= k
+__global__ __launch_bounds__(256) void k_line_band(int n, int k, const int32_t *__restrict__ c, const int *__restrict__ sorted,
+                                                   long long *__restrict__ band)
+{
+    const int m = n - k;
+    const int *sig = sorted, *tau = sorted + n;
+    const long long cnt = (long long)(k + 1) * m;
+    for (long long x = blockIdx.x * (long long)blockDim.x + threadIdx.x; x < cnt; x += (long long)gridDim.x * blockDim.x) {
+        const int d = (int)(x / m), i = (int)(x - (long long)d * m);
+        band[x] = c[(size_t)sig[i] * n + tau[i + d]];
+    }
+}
+
+// one workgroup: the plan above. Scratch (all long long): P (k+1) x (m+1), E m+1, ARG k x (m+1), F / B / L m each.
+__global__ __launch_bounds__(1024) void k_line_unbal(int n, int k, const int32_t *__restrict__ c, const int *__restrict__ sorted,
+                                                     long long *__restrict__ ctl, const long long *__restrict__ band,
+                                                     long long *__restrict__ P, long long *__restrict__ E, long long *__restrict__ ARG,
+                                                     long long *__restrict__ F, long long *__restrict__ Bk, long long *__restrict__ L,
+                                                     int *__restrict__ mcol, long long *__restrict__ v64, int32_t *__restrict__ v32,
+                                                     int *__restrict__ r2c)
+{
+    __shared__ P2 wsum[32];
+    __shared__ int bounds[LINE_KMAX + 2];
+    __shared__ long long s_tot[16];
+    __shared__ int wide;
+    const int t = threadIdx.x, T = blockDim.x;
+    const int m = n - k, m1 = m + 1;
+    const int *sig = sorted, *tau = sorted + n;
+    if (t == 0) wide = 0;
+    // P_d[t+1] = inclusive prefix sums of the band
+    for (int d = 0; d <= k; d++) {
+        long long *Pd = P + (size_t)d * m1;
+        const long long *bd = band + (size_t)d * m;
+        if (t == 0) Pd[0] = 0;
+        wg_scan<OpSum>(m, false, [&](int i) { return P2{bd[i], 0}; }, [&](int i, P2 r) { Pd[i + 1] = r.a; }, wsum);
+    }
+    for (int i = t; i < m1; i += T) E[i] = P[i];
+    __syncthreads();
+    for (int d = 1; d <= k; d++) {
+        const long long *Pd = P + (size_t)d * m1;
+        long long *Ad = ARG + (size_t)(d - 1) * m1;
+        wg_scan<OpMinArg>(m1, false, [&](int i) { return P2{E[i] - Pd[i], (long long)i}; },
+                          [&](int i, P2 r) {
+                              E[i] = Pd[i] + r.a;
+                              Ad[i] = r.b;
+                          },
+                          wsum);
+    }
+    if (t == 0) {
+        int pos = m;
+        bounds[k + 1] = m;
+        for (int d = k; d >= 1; d--) {
+            pos = (int)ARG[(size_t)(d - 1) * m1 + pos];
+            bounds[d] = pos;
+        }
+        bounds[0] = 0;
+    }
+    __syncthreads();
+    // rows: shift, matched column, the adjacent differences along the matched chain
+    long long sum = 0;
+    for (int i = t; i < m; i += T) {
+        int sh = 0;
+        for (int d = 1; d <= k; d++) sh += bounds[d] <= i;
+        mcol[i] = i + sh;
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += T) {
+        const int row = sig[i];
+        int col;
+        if (i < m)
+            col = tau[mcol[i]];
+        else
+            col = tau[bounds[i - m + 1] + (i - m)];   // constant row number d-1 takes the column skipped by step d
+        r2c[row] = col;
+        const int32_t *rp = c + (size_t)row * n;
+        sum += rp[col];
+        if (i < m) {
+            long long f = 0, b = 0;
+            if (i + 1 < m) {
+                const int cn = tau[mcol[i + 1]];
+                const int32_t *rn = c + (size_t)sig[i + 1] * n;
+                f = (long long)rp[cn] - (long long)rp[col];
+                b = (long long)rn[col] - (long long)rn[cn];
+            }
+            F[i] = f;
+            Bk[i] = b;
+        } else {
+            v64[col] = 0;
+            v32[col] = 0;
+        }
+    }
+    __syncthreads();
+    // L_0 = 0, L_{i+1} = min(0, L_i + F_i): inclusive scan of the clamp maps, applied to 0
+    if (t == 0) L[0] = 0;
+    wg_scan<OpClamp>(m - 1, false, [&](int i) { return P2{0, F[i]}; },
+                     [&](int i, P2 r) { L[i + 1] = r.a < r.b ? r.a : r.b; }, wsum);
+    // R_{m-1} = 0, R_i = min(0, R_{i+1} + B_i): the same from the back; price = min(L, R)
+    if (t == 0) {
+        const int col = tau[mcol[m - 1]];
+        const long long pr = L[m - 1] < 0 ? L[m - 1] : 0;
+        v64[col] = pr;
+        v32[col] = (int32_t)pr;
+        if (pr < -(1ll << 30)) wide = 1;
+    }
+    wg_scan<OpClamp>(m - 1, true, [&](int i) { return P2{0, Bk[i]}; },
+                     [&](int i, P2 r) {
+                         const long long R = r.a < r.b ? r.a : r.b;
+                         const long long pr = R < L[i] ? R : L[i];
+                         const int col = tau[mcol[i]];
+                         v64[col] = pr;
+                         v32[col] = (int32_t)pr;
+                         if (pr < -(1ll << 30)) wide = 1;
+                     },
+                     wsum);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((t & 63) == 0) s_tot[t >> 6] = sum;
+    __syncthreads();
+    if (t == 0) {
+        long long tot = 0;
+        for (int j = 0; j < (T >> 6); j++) tot += s_tot[j];
+        ctl[LC_TOTAL] = tot;
+        ctl[LC_FITS32] = !wide;
+    }
 }
 
 // The certificate: row i passes when no cell of the row beats its matched cell, min_j (c[i][j] - v[j]) == c[i][m] - v[m].
@@ -420,17 +657,20 @@ int line_probe_launch(int n, const int32_t *d_cost, const long long **skip_dev)
     return TD_OK;
 }
 
-int line_probe_wait(int *plausible)
+int line_probe_wait(int *mode, int *k)
 {
     Ctx &c = ctx();
     TD_HIP(hipEventSynchronize(g_probe_done));
-    *plausible = *(volatile const long long *)((char *)c.pinned + VERDICT_OFF) != 0;
+    const volatile long long *h = (const volatile long long *)((char *)c.pinned + VERDICT_OFF);
+    *mode = (int)h[0];
+    *k = (int)h[1];
     return TD_OK;
 }
 
-// The sorted matching on the n x n device matrix (after a "plausible" probe). *accepted = 1: *r2c_dev points at the
-// library's device copy of row_to_col and *total is its cost, proven optimal by the certificate pass.
-int line_finish(int n, const int32_t *d_cost, const int32_t **r2c_dev, int64_t *total, int *accepted)
+// The sorted matching on the n x n device matrix (after a "plausible" probe; k > 0: the last k rows of the sorted
+// order are constant rows, verdict 3). *accepted = 1: *r2c_dev points at the library's device copy of row_to_col
+// and *total is its cost, proven optimal by the certificate pass.
+int line_finish(int n, int k, const int32_t *d_cost, const int32_t **r2c_dev, int64_t *total, int *accepted)
 {
     Ctx &c = ctx();
     *accepted = 0;
@@ -454,9 +694,26 @@ int line_finish(int n, const int32_t *d_cost, const int32_t **r2c_dev, int64_t *
         TD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin, kout, vin, vout, 2 * n, 0, 64, c.stream));
         if ((rc = ensure(g_lw.tmp, bytes + 256))) return rc;
         TD_HIP(hipcub::DeviceRadixSort::SortPairs(g_lw.tmp.p, bytes, kin, kout, vin, vout, 2 * n, 0, 64, c.stream));
-        k_line_gather<<<std::max(1, std::min(c.n_cu * 4, (n + 255) / 256)), 256, 0, c.stream>>>(n, d_cost, vout, ctl, (long long *)g_lw.f.p,
-                                                                                            (int *)g_lw.r2c.p);
-        k_line_scan<<<1, 1024, 0, c.stream>>>(n, vout, ctl, (const long long *)g_lw.f.p, (long long *)g_lw.v64.p, (int32_t *)g_lw.v32.p);
+        if (k == 0) {
+            k_line_gather<<<std::max(1, std::min(c.n_cu * 4, (n + 255) / 256)), 256, 0, c.stream>>>(n, d_cost, vout, ctl, (long long *)g_lw.f.p,
+                                                                                                (int *)g_lw.r2c.p);
+            k_line_scan<<<1, 1024, 0, c.stream>>>(n, vout, ctl, (const long long *)g_lw.f.p, (long long *)g_lw.v64.p, (int32_t *)g_lw.v32.p);
+        } else {
+            const size_t n1 = (size_t)n + 1;
+            if ((rc = ensure(g_lw.band, 8 * (size_t)(k + 1) * n1))) return rc;
+            if ((rc = ensure(g_lw.P, 8 * (size_t)(k + 1) * n1))) return rc;
+            if ((rc = ensure(g_lw.ARG, 8 * (size_t)k * n1))) return rc;
+            if ((rc = ensure(g_lw.E, 8 * n1))) return rc;
+            if ((rc = ensure(g_lw.Bk, 8 * n1))) return rc;
+            if ((rc = ensure(g_lw.L, 8 * n1))) return rc;
+            if ((rc = ensure(g_lw.mcol, 4 * n1))) return rc;
+            k_line_band<<<std::max(1, std::min(c.n_cu * 4, (int)(((size_t)(k + 1) * n + 255) / 256))), 256, 0, c.stream>>>(
+                n, k, d_cost, vout, (long long *)g_lw.band.p);
+            k_line_unbal<<<1, 1024, 0, c.stream>>>(n, k, d_cost, vout, ctl, (const long long *)g_lw.band.p, (long long *)g_lw.P.p,
+                                                    (long long *)g_lw.E.p, (long long *)g_lw.ARG.p, (long long *)g_lw.f.p,
+                                                    (long long *)g_lw.Bk.p, (long long *)g_lw.L.p, (int *)g_lw.mcol.p,
+                                                    (long long *)g_lw.v64.p, (int32_t *)g_lw.v32.p, (int *)g_lw.r2c.p);
+        }
         TD_HIP(hipGetLastError());
     }
     {
@@ -488,7 +745,8 @@ void line_release_workspace()
 {
     if (g_probe_done) (void)hipEventDestroy(g_probe_done);
     g_probe_done = nullptr;
-    Buf *bs[] = {&g_lw.ctl, &g_lw.kin, &g_lw.kout, &g_lw.vin, &g_lw.vout, &g_lw.tmp, &g_lw.f, &g_lw.v64, &g_lw.v32, &g_lw.r2c};
+    Buf *bs[] = {&g_lw.ctl, &g_lw.kin,  &g_lw.kout, &g_lw.vin, &g_lw.vout, &g_lw.tmp, &g_lw.f,  &g_lw.v64, &g_lw.v32,
+                 &g_lw.r2c, &g_lw.band, &g_lw.P,    &g_lw.E,   &g_lw.ARG,  &g_lw.Bk,  &g_lw.L,  &g_lw.mcol};
     for (Buf *b : bs) {
         if (b->p) (void)hipFree(b->p);
         b->p = nullptr;

@@ -136,3 +136,54 @@ def test_default_path_on_every_instance_family(line_on):
             check_assignment(td, c)
             if kind == "g2" and n >= 17:
                 assert td.last_stats()["line_metric"] == 1
+
+
+def padded_line_cost(rng, n_cabs, n_req, S, big=250000):
+    """greedy_opt.py:86-99 for |i-j| stands: n = max, the missing side is big_cost"""
+    a = rng.integers(0, S, n_cabs)
+    b = rng.integers(0, S, n_req)
+    n = max(n_cabs, n_req)
+    c = np.full((n, n), big, np.int32)
+    c[:n_cabs, :n_req] = np.abs(a[:, None] - b[None, :])
+    return c
+
+
+@pytest.mark.parametrize("side", ["fewer_cabs", "fewer_requests"])
+def test_unbalanced_line_models(line_on, side):
+    """k = 1..8 missing cabs (constant rows) or requests (constant columns, solved on the transpose): the
+    certified plan must give the oracle's total; k = 9 is past LINE_KMAX and goes to the general solver"""
+    td = line_on
+    rng = np.random.default_rng(21 if side == "fewer_cabs" else 22)
+    for n in (5, 12, 40, 130, 400, 515):
+        for k in (1, 2, 3, 5, 8, 9):
+            if n - k < 2:
+                continue
+            for S in (4, 60, 10 * n):
+                c = padded_line_cost(rng, n - k, n, S) if side == "fewer_cabs" else padded_line_cost(rng, n, n - k, S)
+                r2c, total, dual = td.assign(c, want_dual=True)
+                assert sorted(r2c.tolist()) == list(range(n))
+                assert int(c[np.arange(n), r2c].astype(np.int64).sum()) == total == dual
+                assert total == oracle.assign(c)[0], (side, n, k, S)
+                st = td.last_stats()
+                if k <= 8 and S == 10 * n:
+                    assert st["line_metric"] == 1 and st["line_dummies"] == k, (side, n, k, S, st)
+                    assert st["transposed"] == (1 if side == "fewer_requests" else 0)
+                if k == 9:
+                    assert st["line_metric"] == 0
+
+
+def test_unbalanced_line_large_against_general_solver(line_on):
+    """n = 4096 with 3 missing cabs / 2 missing requests: certified plan vs the general solver's optimum"""
+    import torch
+    td = line_on
+    rng = np.random.default_rng(23)
+    n = 4096
+    for n_cabs, n_req in ((n - 3, n), (n, n - 2)):
+        c = torch.from_numpy(padded_line_cost(rng, n_cabs, n_req, 10 * n)).cuda()
+        r2c, t_line, dual = td.assign(c, want_dual=True)
+        assert td.last_stats()["line_metric"] == 1 and dual == t_line
+        assert sorted(r2c.tolist()) == list(range(n))
+        td.set_line_metric(False)
+        _, t_gen = td.assign(c)
+        td.set_line_metric(True)
+        assert t_line == t_gen

@@ -19,6 +19,10 @@ elif kind == "g2":
 elif kind == "g3":
     a = rng.integers(0, 50, n).astype(np.int32); b = rng.integers(0, 50, max(1, int(0.363 * n))).astype(np.int32)
     td.cost_build(a, b, None, fill=250000, threshold=10, out=ct)
+elif kind == "geo2":   # 2-D city grid, Manhattan distance (not in the reference: its table is a line)
+    side = int(os.environ.get("GEO_SIDE", "4000"))
+    ax, ay, bx, by = (torch.from_numpy(rng.integers(0, side, n).astype(np.int32)).cuda() for _ in range(4))
+    ct.copy_((ax[:, None] - bx[None, :]).abs() + (ay[:, None] - by[None, :]).abs())
 else:
     ct.copy_(torch.from_numpy(rng.integers(0, 10**6, (n, n)).astype(np.int32)))
 r2c = torch.empty(n, dtype=torch.int32, device="cuda")
@@ -31,4 +35,11 @@ for rep in range(reps):
     ts.append(time.perf_counter() - t0)
 st = td.last_stats()
 env = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("TD_") and k != "TD_DEBUG")
+if os.environ.get("PROF"):
+    _ffi.check(lib.td_profile_enable(1)); _ffi.check(lib.td_profile_reset())
+    _ffi.check(lib.td_assign(n, ct.data_ptr(), r2c.data_ptr(), ctypes.byref(tot), ctypes.byref(dual)))
+    for name, k in _ffi.TD_K.items():
+        ms = ctypes.c_double(0); cnt = ctypes.c_int64(0)
+        _ffi.check(lib.td_profile_get(k, ctypes.byref(ms), ctypes.byref(cnt)))
+        if cnt.value: print(f"   {name:10s} {ms.value:9.3f} ms {cnt.value:6d} launches", flush=True)
 print(f"{kind} n={n} [{env}]: {1e3*min(ts):.3f} ms total={tot.value} cert={'ok' if tot.value == dual.value else 'FAIL'} {st}", flush=True)
