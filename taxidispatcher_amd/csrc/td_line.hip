@@ -37,7 +37,7 @@ namespace {
 // LC_PLAUS: 0 refused; 1 balanced line metric plausible; 2 constant trailing COLUMNS (retry on the transpose);
 //           3 plausible with LC_K constant rows (the unbalanced model: fewer cabs than requests)
 enum { LC_P = 0, LC_Q, LC_I1, LC_I2, LC_PLAUS, LC_REV, LC_FAIL, LC_FITS32, LC_TOTAL, LC_K, LC_FILL, LC_WORDS };
-constexpr int LINE_KMAX = 8;   // most constant rows the unbalanced plan is made for
+constexpr int LINE_KMAX = 32;   // most constant rows the unbalanced plan is made for
 
 struct LineWs {
     Buf ctl, kin, kout, vin, vout, tmp, f, v64, v32, r2c;
@@ -118,7 +118,19 @@ __global__ __launch_bounds__(1024) void k_line_probe(int n, const int32_t *__res
     const bool rows_dummy = !__syncthreads_or(rowvar);
     const bool cols_dummy = !__syncthreads_or(colvar);
     if (cols_dummy) {
-        mode = rows_dummy ? 0 : 2;
+        // before the host pays for a transpose: columns 0 and 1 over the first 1024 ROWS must pass step 0 too
+        // (a thresholded simulator model with dummy requests is refused here)
+        const long long wc = c[1];
+        const long long Ga = u0 + wc, Gb = labs64(u0 - wc);
+        int bad_c = 0, bad_d = 0;
+        if (t < n) {
+            const long long xx = c[(size_t)t * n], yy = c[(size_t)t * n + 1];
+            bad_c = !span_ok(xx, yy, Ga);
+            bad_d = !span_ok(xx, yy, Gb);
+        }
+        bad_c = __syncthreads_or(bad_c);
+        bad_d = __syncthreads_or(bad_d);
+        mode = (rows_dummy || (bad_c && bad_d)) ? 0 : 2;
     } else if (!(bad_a && bad_b)) {
         ArgMax x;
         x.v = LLONG_MIN, x.i = 0x7fffffff;
