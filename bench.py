@@ -399,8 +399,76 @@ def main():
     stats = td.last_stats()
 
     prof = kernel_profile(wl, ffi, reps=3) if rank == 0 else {}
+
+    def build_line(shard_res):
+        n = args.n
+        ms_per_step = 1e3 * dt / args.steps
+        value = world * n * args.steps / dt
+        # roofline: the dominant KERNEL of a step by device time.  Classes that are one launch of one
+        # streaming kernel (cost write, compress, LCM) are compared directly; "bid" / "assign" / "sap"
+        # are many launches of several different kernels (the largest single one, bidding round 0, is
+        # ~1/3 of compress), so they are reported as a class but never priced as one kernel.
+        alg_bytes = {"gen": 4.0 * n * n, "cost_build": 4.0 * n * n, "compress": 4.0 * n * n, "lcm": 4.0 * n * n,
+                     "cert": 4.0 * n * n}   # cert = the certificate pass of the line-metric path (td_line.hip): one read of the matrix
+        streaming = [k for k in prof if k in alg_bytes and prof[k]["launches"] <= 2]
+        dom = max(streaming, key=lambda k: prof[k]["total_ms"]) if streaming else None
+        roof = None
+        if dom:
+            p = prof[dom]
+            b = alg_bytes[dom]
+            achieved = b / (p["avg_us"] * 1e-6) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom), "traffic_source": TRAFFIC_PROFILE,
+                    "algorithmic_bytes_per_launch": b, "avg_launch_us": p["avg_us"], "launches_per_step": p["launches"],
+                    "largest_class_by_time": max(prof, key=lambda k: prof[k]["total_ms"])}
+        line = {
+            "metric": "NxN assignments/sec", "value": value, "unit": "assignments/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "%s N=%d: device cost write (4N^2 B) + exact assignment, total checked == optimum"
+                                   % (args.workload, n), "n": n, "instances_per_step": world,
+                       "parallelism": "independent instance per GPU, no collective" if world > 1 else "single GPU"},
+            "pairs_per_s": world * float(n) * n * args.steps / dt,
+            "whole_step_algorithmic_GBps": 8.0 * n * n * world * args.steps / dt / 1e9,
+            "total_cost": int(total), "solver_stats": stats, "kernels": prof, "roofline": roof,
+        }
+        if args.line_metric == "off":
+            line["config"]["line_metric_attempt"] = "off"
+        if shard_res is not None:
+            line["sharded_single_instance"] = shard_res
+            if world > 1 and args.multi_mode == "sharded" and "error" not in shard_res:
+                # multi-GPU headline = BASELINE configs[3]; the replicas figure measured above moves to a side field
+                line["replicas"] = {"value": value, "ms_per_step": ms_per_step, "scaling": "weak",
+                                    "workload": line["config"]["workload"] + " (one independent instance per GPU, no collective)"}
+                sn = shard_res["n"]
+                line.update({"value": shard_res["assignments_per_s"], "ms_per_step": shard_res["ms_per_step"],
+                             "scaling": "strong",
+                             "config": {"workload": shard_res["workload"], "n": sn, "instances_per_step": 1,
+                                        "parallelism": "rows sharded over %d GPUs, RCCL MAX all-reduce per bidding round" % world},
+                             "pairs_per_s": float(sn) * sn * 1e3 / shard_res["ms_per_step"],
+                             "whole_step_algorithmic_GBps": 8.0 * sn * sn / (shard_res["ms_per_step"] * 1e-3) / 1e9,
+                             "total_cost": shard_res["total_cost"]})
+        return line
+
     shard_res, single_ref = None, None
+    watchdog = None
     if world > 1 or args.force_sharded:
+        # a collective that never returns on some rank (RCCL / IPC trouble on a node this path has not seen) must
+        # not take the whole run with it: after TD_BENCH_SHARD_TIMEOUT seconds every rank leaves, rank 0 having
+        # printed the replicas line with the sharded leg marked as timed out
+        import threading
+        limit = float(os.environ.get("TD_BENCH_SHARD_TIMEOUT", "240"))
+
+        def bail():
+            if rank == 0:
+                out = build_line({"error": "sharded leg did not finish within %.0f s (watchdog); replicas figure reported" % limit})
+                sys.stdout.flush()
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(limit, bail)
+        watchdog.daemon = True
+        watchdog.start()
         dist.barrier()
         if args.sharded_n > 0:
             del wl.cost
@@ -414,56 +482,13 @@ def main():
             except Exception as e:  # keep the replicas line even if this leg fails
                 shard_res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         dist.barrier()
+    if watchdog is not None:
+        watchdog.cancel()
     if rank != 0:
         dist.destroy_process_group()
         return
+    line = build_line(shard_res)
     n = args.n
-    ms_per_step = 1e3 * dt / args.steps
-    value = world * n * args.steps / dt
-    # roofline: the dominant KERNEL of a step by device time.  Classes that are one launch of one
-    # streaming kernel (cost write, compress, LCM) are compared directly; "bid" / "assign" / "sap"
-    # are many launches of several different kernels (the largest single one, bidding round 0, is
-    # ~1/3 of compress), so they are reported as a class but never priced as one kernel.
-    alg_bytes = {"gen": 4.0 * n * n, "cost_build": 4.0 * n * n, "compress": 4.0 * n * n, "lcm": 4.0 * n * n,
-                 "cert": 4.0 * n * n}   # cert = the certificate pass of the line-metric path (td_line.hip): one read of the matrix
-    streaming = [k for k in prof if k in alg_bytes and prof[k]["launches"] <= 2]
-    dom = max(streaming, key=lambda k: prof[k]["total_ms"]) if streaming else None
-    roof = None
-    if dom:
-        p = prof[dom]
-        b = alg_bytes[dom]
-        achieved = b / (p["avg_us"] * 1e-6) / 1e9
-        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom), "traffic_source": TRAFFIC_PROFILE,
-                "algorithmic_bytes_per_launch": b, "avg_launch_us": p["avg_us"], "launches_per_step": p["launches"],
-                "largest_class_by_time": max(prof, key=lambda k: prof[k]["total_ms"])}
-    line = {
-        "metric": "NxN assignments/sec", "value": value, "unit": "assignments/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "%s N=%d: device cost write (4N^2 B) + exact assignment, total checked == optimum"
-                               % (args.workload, n), "n": n, "instances_per_step": world,
-                   "parallelism": "independent instance per GPU, no collective" if world > 1 else "single GPU"},
-        "pairs_per_s": world * float(n) * n * args.steps / dt,
-        "whole_step_algorithmic_GBps": 8.0 * n * n * world * args.steps / dt / 1e9,
-        "total_cost": int(total), "solver_stats": stats, "kernels": prof, "roofline": roof,
-    }
-    if args.line_metric == "off":
-        line["config"]["line_metric_attempt"] = "off"
-    if shard_res is not None:
-        line["sharded_single_instance"] = shard_res
-        if world > 1 and args.multi_mode == "sharded" and "error" not in shard_res:
-            # multi-GPU headline = BASELINE configs[3]; the replicas figure measured above moves to a side field
-            line["replicas"] = {"value": value, "ms_per_step": ms_per_step, "scaling": "weak",
-                                "workload": line["config"]["workload"] + " (one independent instance per GPU, no collective)"}
-            sn = shard_res["n"]
-            line.update({"value": shard_res["assignments_per_s"], "ms_per_step": shard_res["ms_per_step"],
-                         "scaling": "strong",
-                         "config": {"workload": shard_res["workload"], "n": sn, "instances_per_step": 1,
-                                    "parallelism": "rows sharded over %d GPUs, RCCL MAX all-reduce per bidding round" % world},
-                         "pairs_per_s": float(sn) * sn * 1e3 / shard_res["ms_per_step"],
-                         "whole_step_algorithmic_GBps": 8.0 * sn * sn / (shard_res["ms_per_step"] * 1e-3) / 1e9,
-                         "total_cost": shard_res["total_cost"]})
     if world == 1 and not args.no_extras and args.workload == "g1":
         # the other workloads of SURVEY 8d / BASELINE configs, measured in the same run (side fields)
         extras = {}
