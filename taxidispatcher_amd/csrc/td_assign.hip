@@ -140,6 +140,7 @@ int g_speculate = 1;        // TD_SPECULATE     try u8 storage without waiting f
 int g_sap8 = 1;             // TD_SAP8          lean u8 finisher
 int g_psap8_batches = 1;    // TD_PSAP8         speculative batches of the lean u8 search
 int g_psap8_grid = 64;      // TD_PSAP8_GRID    searches per such batch
+int g_wide_u16_n = 8192;    // TD_WIDE_U16_N    wide, tie-free 2-byte rows of n >= this are redone as 4-byte cells with 32-bit prices (0: never)
 bool g_line = true;         // TD_LINE          0: skip the line-metric recogniser (td_line.hip), always run the general solver
 int g_line_min_n = 2;       // TD_LINE_MIN_N    smallest n the recogniser is tried on
 int g_psap_batches = 16;    // TD_PSAP          speculative batches per group of the generic search (u16 / u32 rows)
@@ -203,6 +204,7 @@ void read_tunables()
     if (const char *e = getenv("TD_DEFER_CONST")) g_defer_const = atoi(e) != 0;
     if (const char *e = getenv("TD_SHAPE")) g_shape = atoi(e) != 0;
     if (const char *e = getenv("TD_SHAPE_MAX_N")) g_shape_max_n = atoi(e);
+    if (const char *e = getenv("TD_WIDE_U16_N")) g_wide_u16_n = std::max(0, atoi(e));
     if (const char *e = getenv("TD_LINE")) g_line = atoi(e) != 0;
     if (const char *e = getenv("TD_LINE_MIN_N")) g_line_min_n = std::max(2, atoi(e));
     if (const char *e = getenv("TD_PSAP8_GRID")) g_psap8_grid = std::max(1, std::min(192, atoi(e)));
@@ -3197,6 +3199,14 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
             const int nfree_now = ((int *)c.pinned)[CTL_NFREE], tied0 = ((int *)c.pinned)[CTL_TIED];
             wide = !(nfree_now < std::max(g_warm_minfree, n / 64) || (long long)tied0 * 16 * 8 > n);   // tied0 counts every 16th row
             c.stats[2] = nfree_now;
+        }
+        if (wide && bpc == 2 && g_wide_u16_n && n >= g_wide_u16_n && g_narrow_price && !np_failed && known_range >= 0 &&
+            known_range <= NP_RANGE) {
+            // A hard instance (the finisher will dominate) in 2-byte cells: the cooperative finisher k_sapx needs
+            // n / E >= 8 * 256 chunks and the 2-byte kernels carry 64-bit prices.  Redo it as 4-byte cells with
+            // 32-bit prices (the next width of the loop): one more compress pass and 12 rounds, milliseconds
+            // against hundreds (2-D Manhattan grid, n = 8192: 493 -> 224 ms, n = 16 384: 848 -> 640 ms).
+            continue;
         }
         if (wide) {
             // eps > 0 phases down to eps = 1 as a price warm start (sv_warm_t), the rounds once more,

@@ -587,3 +587,24 @@ def test_workspace_reuse_across_sizes(td):
             assert first[key][1] == total and np.array_equal(first[key][0], r2c)
         first[key] = (r2c, total)
     del rng
+
+
+def test_wide_two_byte_rows_redone_with_narrow_prices(td):
+    """2-D Manhattan grid, n = 8192: rows fit 2-byte cells, the instance is wide and tie-free, so the solve is
+    redone as 4-byte cells with 32-bit prices (TD_WIDE_U16_N) for the cooperative finisher; exact by the device
+    certificate, the oracle on a sub-instance of the same family."""
+    import torch
+    rng = np.random.default_rng(31)
+    for n, check_oracle in ((600, True), (8192, False)):
+        ax, ay, bx, by = (rng.integers(0, 4000, n).astype(np.int32) for _ in range(4))
+        c = np.abs(ax[:, None] - bx[None, :]) + np.abs(ay[:, None] - by[None, :])
+        ct = torch.from_numpy(c.astype(np.int32)).cuda()
+        r2c, total, dual = td.assign(ct, n, want_dual=True)
+        assert total == dual
+        assert sorted(r2c.tolist()) == list(range(n))
+        assert int(c[np.arange(n), r2c].astype(np.int64).sum()) == total
+        st = td.last_stats()
+        if check_oracle:
+            assert total == oracle.assign(c.astype(np.int32))[0]
+        else:
+            assert st["bytes_per_cell"] == 4 and st["narrow_price"] == 1 and st["warm_rounds"] > 0
