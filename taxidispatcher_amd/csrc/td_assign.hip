@@ -140,7 +140,7 @@ int g_speculate = 1;        // TD_SPECULATE     try u8 storage without waiting f
 int g_sap8 = 1;             // TD_SAP8          lean u8 finisher
 int g_psap8_batches = 1;    // TD_PSAP8         speculative batches of the lean u8 search
 int g_psap8_grid = 64;      // TD_PSAP8_GRID    searches per such batch
-int g_wide_u16_n = 8192;    // TD_WIDE_U16_N    wide, tie-free 2-byte rows of n >= this are redone as 4-byte cells with 32-bit prices (0: never)
+int g_wide_u16_n = 4096;    // TD_WIDE_U16_N    wide, tie-free 2-byte rows of n >= this are redone as 4-byte cells with 32-bit prices (0: never)
 bool g_line = true;         // TD_LINE          0: skip the line-metric recogniser (td_line.hip), always run the general solver
 int g_line_min_n = 2;       // TD_LINE_MIN_N    smallest n the recogniser is tried on
 int g_psap_batches = 16;    // TD_PSAP          speculative batches per group of the generic search (u16 / u32 rows)
@@ -156,6 +156,7 @@ int g_warm_min_range = 256; // TD_WARM_MIN_RANGE rows narrower than this are nev
 int g_warm_minfree = 32;    // TD_WARM_MINFREE  free rows after the eps = 0 rounds below which the finisher is cheaper
 int g_sapx = 1;             // TD_SAPX          cooperative multi-workgroup serial finisher (k_sapx)
 int g_sapx_min = 8;         // TD_SAPX_MIN      fewest workgroups (256 chunks each) for which it is used
+int g_sapx_rows = 24;       // TD_SAPX_ROWS     ... half of that when at least this many rows are left for it
 int g_sap512 = 1;           // TD_SAP512        512-thread generic finisher (double register budget) for n <= 8192
 int g_psap_worth = 4;       // TD_PSAP_WORTH    rows a batch must commit on average for another group to be launched
 int g_defer_const = 1;      // TD_DEFER_CONST   constant rows sit out the solve (k_place_const)
@@ -192,6 +193,7 @@ void read_tunables()
     if (const char *e = getenv("TD_WARM_MIN_RANGE")) g_warm_min_range = std::max(1, atoi(e));
     if (const char *e = getenv("TD_WARM_MINFREE")) g_warm_minfree = std::max(1, atoi(e));
     if (const char *e = getenv("TD_SAPX_MIN")) g_sapx_min = std::max(1, atoi(e));
+    if (const char *e = getenv("TD_SAPX_ROWS")) g_sapx_rows = std::max(1, atoi(e));
     if (const char *e = getenv("TD_PSAP_WORTH")) g_psap_worth = std::max(1, atoi(e));
     if (const char *e = getenv("TD_SPECULATE")) g_speculate = atoi(e) != 0;
     if (const char *e = getenv("TD_LDS_GRID")) g_lds_grid = std::max(1, std::min(8, atoi(e)));
@@ -2687,6 +2689,7 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
     k_freelist<<<1, 1024, 0, ctx().stream>>>(n, r2c_full, (int *)sv.list.p, (int *)sv.misc.p);
     // ---- speculative parallel searches first (a few batches), the serial workgroup mops up
     // (u8 instances go straight to the lean tie-batching serial workgroup, which is faster there)
+    int nfree_left = -1;   // free rows the speculative batches left (-1: not read back)
     if (g_psap_batches > 0 && CH <= 4 && CH * E <= 16 && lds && n >= 64 && sizeof(CT) > 1) {
         Ctx &c = ctx();
         using PT = typename Tr<CT>::PT;
@@ -2745,6 +2748,7 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
             nfree = left;
             if (!worth) break;
         }
+        nfree_left = nfree;
     }
     {   // cooperative finisher: the columns of one search split over several CUs, 256-thread
         // workgroups.  Launched with hipLaunchCooperativeKernel: its grid barrier needs every
@@ -2758,7 +2762,10 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
         const int KX = (nchunks + TXsel - 1) / TXsel;
         const bool lean8 = sizeof(CT) == 1 && CH == 1 && g_sap8;
         bool launched_x = false;
-        if (g_sapx && !lean8 && KX * TXsel >= g_sapx_min * 256 && KX <= SX_KMAX) {
+        // from 8 x 256 chunks on always; from 4 x 256 on when many rows are left (|a-b| n = 6000: 190 -> 109 ms with 62 rows;
+        // uniform 0..10^6 n = 4096 with 10 rows: 9.8 -> 12.1 ms, so not for a handful)
+        const bool big = KX * TXsel >= g_sapx_min * 256 || (KX * TXsel >= g_sapx_min * 128 && nfree_left >= g_sapx_rows);
+        if (g_sapx && !lean8 && big && KX <= SX_KMAX) {
             Ctx &c = ctx();
             using PT = typename Tr<CT>::PT;
             int rc = ensure(sv.xbuf, sizeof(SxShared));
