@@ -3077,7 +3077,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     // and keeps it only if its certificate pass proves it optimal on this matrix.  The probe is queued in
     // front of the first compress pass and its verdict is awaited while that pass runs, so a refusal costs
     // the probe kernel alone; when the probe says "plausible" the compress pass returns at once (sv.skip).
-    bool line_pending = false;
+    bool line_pending = false, early_check = false;
     c.stats[8] = c.stats[9] = 0;
     if (g_line && n >= g_line_min_n && !g_solver_eps) {
         if ((rc = line_probe_launch(n, sv.d_cost, &sv.skip))) return rc;
@@ -3107,8 +3107,9 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         if (line_pending) {
             line_pending = false;
             sv.skip = nullptr;
-            int mode = 0, kd = 0, accepted = 0;
-            if ((rc = line_probe_wait(&mode, &kd))) return rc;
+            int mode = 0, kd = 0, accepted = 0, susp = 0;
+            if ((rc = line_probe_wait(&mode, &kd, &susp))) return rc;
+            early_check = susp != 0;
             if (mode) {
                 const int32_t *res = nullptr;
                 bool line_t = false;
@@ -3157,6 +3158,23 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         TD_DISPATCH(sv, sv_begin_t, sv);
         sv.probe = nullptr;
         if (rc) return rc;
+        if (spec && early_check) {
+            // the line probe saw a row too wide for one byte or a constant last column: this speculative attempt
+            // will most likely be void (width flag, or the shape probe asking for the transpose).  One round trip
+            // now instead of the ~30 launches of rounds and finishers that would exit at once.
+            early_check = false;
+            int ef = 0;
+            if ((rc = sv_readback(sv, nullptr, nullptr, 0, &ef))) return rc;
+            if (ef & 4) {
+                want_transpose = true;
+                range_hint = c.stats[6] > 254 ? c.stats[6] : -1;
+                break;
+            }
+            if (ef) {
+                known_range = c.stats[6];
+                continue;
+            }
+        }
         int64_t warm_rounds = 0;
         if (g_solver_eps) {
             int64_t er = 0, ep = 0;

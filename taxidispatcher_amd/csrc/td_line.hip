@@ -104,19 +104,23 @@ __global__ __launch_bounds__(1024) void k_line_probe(int n, const int32_t *__res
     const long long Ea = u0 + w0, Eb = labs64(u0 - w0);
     const long long B0 = c[(size_t)(n - 1) * n], B1 = c[n - 1];
     int mode = 0, rev = 0, q = -1, rq = 0, i2 = -1, kdummy = 0;
-    int bad_a = 0, bad_b = 0, rowvar = 0, colvar = 0;
+    int bad_a = 0, bad_b = 0, rowvar = 0, colvar = 0, far = 0;
     if (t == 0) s_cnt = 0;
     if (t < n) {
         const long long xx = c[t], yy = c[(size_t)n + t];
         bad_a = !span_ok(xx, yy, Ea);
         bad_b = !span_ok(xx, yy, Eb);
         rowvar = c[(size_t)(n - 1) * n + t] != B0;
+        far = labs64(xx - u0) > 254;   // row 0 cannot be stored in one byte per cell
     }
     if (t < nsamp) colvar = c[(size_t)(t * step) * n + (n - 1)] != B1;
     bad_a = __syncthreads_or(bad_a);
     bad_b = __syncthreads_or(bad_b);
     const bool rows_dummy = !__syncthreads_or(rowvar);
     const bool cols_dummy = !__syncthreads_or(colvar);
+    // a hint for td_assign's speculative 1-byte attempt: it will fail (row 0 is too wide) or is likely to ask for the
+    // transpose (constant last column): worth one early look at its flag instead of ~30 launches that exit at once
+    const int suspicious = __syncthreads_or(far) || cols_dummy;
     if (cols_dummy) {
         // before the host pays for a transpose: columns 0 and 1 over the first 1024 ROWS must pass step 0 too
         // (a thresholded simulator model with dummy requests is refused here)
@@ -235,6 +239,7 @@ __global__ __launch_bounds__(1024) void k_line_probe(int n, const int32_t *__res
         ctl[LC_FILL] = B0;
         host_verdict[0] = mode;
         host_verdict[1] = kdummy;
+        host_verdict[2] = suspicious;
         __threadfence_system();
     }
 }
@@ -669,13 +674,14 @@ int line_probe_launch(int n, const int32_t *d_cost, const long long **skip_dev)
     return TD_OK;
 }
 
-int line_probe_wait(int *mode, int *k)
+int line_probe_wait(int *mode, int *k, int *suspicious)
 {
     Ctx &c = ctx();
     TD_HIP(hipEventSynchronize(g_probe_done));
     const volatile long long *h = (const volatile long long *)((char *)c.pinned + VERDICT_OFF);
     *mode = (int)h[0];
     *k = (int)h[1];
+    if (suspicious) *suspicious = (int)h[2];
     return TD_OK;
 }
 
