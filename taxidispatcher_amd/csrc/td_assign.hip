@@ -3077,7 +3077,8 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     // and keeps it only if its certificate pass proves it optimal on this matrix.  The probe is queued in
     // front of the first compress pass and its verdict is awaited while that pass runs, so a refusal costs
     // the probe kernel alone; when the probe says "plausible" the compress pass returns at once (sv.skip).
-    bool line_pending = false, early_check = false;
+    bool line_pending = false, early_check = false, r2c_in_pinned = false;
+    constexpr size_t R2C_PIN_OFF = 8192;   // clear of the control words (0..), the totals (1024) and the probe verdict (4096)
     c.stats[8] = c.stats[9] = 0;
     if (g_line && n >= g_line_min_n && !g_solver_eps) {
         if ((rc = line_probe_launch(n, sv.d_cost, &sv.skip))) return rc;
@@ -3254,6 +3255,11 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         TD_DISPATCH(sv, sv_totals_t, sv, dual_bound != nullptr);
         if (rc) return rc;
         int flag = 0;
+        // a host row_to_col of a small model rides along with the read-back (one round trip, no blocking pageable copy)
+        r2c_in_pinned = !is_device_ptr(row_to_col) && (size_t)R2C_PIN_OFF + sizeof(int32_t) * (size_t)n <= c.pinned_cap;
+        if (r2c_in_pinned)
+            TD_HIP(hipMemcpyAsync((char *)c.pinned + R2C_PIN_OFF, transposed ? sv.owner.p : sv.r2c.p, sizeof(int32_t) * (size_t)n,
+                                  hipMemcpyDeviceToHost, c.stream));
         if ((rc = sv_readback(sv, &tot, &dual, max_rounds, (spec || bpc == 5) ? &flag : nullptr))) return rc;
         c.stats[1] = warm_rounds;
         if (bpc == 5 && flag) {   // a price reached the 32-bit limit: the attempt is void, redo with 64-bit prices
@@ -3287,6 +3293,12 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     // transposed solve: its columns are the caller's rows, owner[] is the caller's row_to_col
     const void *res = transposed ? sv.owner.p : sv.r2c.p;
     c.stats[7] = transposed ? 1 : 0;
+    if (r2c_in_pinned) {
+        memcpy(row_to_col, (const char *)c.pinned + R2C_PIN_OFF, sizeof(int32_t) * (size_t)n);
+        if (total) *total = tot;
+        if (dual_bound) *dual_bound = dual;
+        return TD_OK;
+    }
     if (is_device_ptr(row_to_col)) {
         TD_HIP(hipMemcpyAsync(row_to_col, res, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c.stream));
     } else {

@@ -29,6 +29,10 @@ struct Ctx {
     Buf lcm_a, lcm_b, lcm_c, lcm_d;
     void *pinned = nullptr;  // small pinned host block for result read-back
     size_t pinned_cap = 0;
+    // pinned bounce ring for SMALL host inputs (position arrays): a pageable hipMemcpyAsync blocks the host for
+    // ~10 us per call, a host memcpy into this ring + an async copy from it does not
+    void *pin_in = nullptr;
+    size_t pin_in_cap = 0, pin_in_off = 0;
     // profiling
     bool prof = false;
     double prof_ms[TD_K_COUNT] = {0};

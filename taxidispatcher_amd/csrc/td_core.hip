@@ -65,7 +65,21 @@ int to_device(const void *src, size_t bytes, Buf &stage, const void **out)
     }
     int rc = ensure(stage, bytes);
     if (rc) return rc;
-    TD_HIP(hipMemcpyAsync(stage.p, src, bytes, hipMemcpyHostToDevice, g_ctx.stream));
+    Ctx &c = g_ctx;
+    if (c.pin_in && bytes > 0 && bytes <= 32768) {
+        // small input: through the pinned ring (the slot is reused only after a stream synchronisation at wrap-around)
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        if (c.pin_in_off + need > c.pin_in_cap) {
+            TD_HIP(hipStreamSynchronize(c.stream));
+            c.pin_in_off = 0;
+        }
+        void *slot = (char *)c.pin_in + c.pin_in_off;
+        c.pin_in_off += need;
+        memcpy(slot, src, bytes);
+        TD_HIP(hipMemcpyAsync(stage.p, slot, bytes, hipMemcpyHostToDevice, c.stream));
+    } else {
+        TD_HIP(hipMemcpyAsync(stage.p, src, bytes, hipMemcpyHostToDevice, c.stream));
+    }
     *out = stage.p;
     return TD_OK;
 }
@@ -316,6 +330,9 @@ int td_init(int device)
     c.device = device;
     c.pinned_cap = 1 << 16;
     TD_HIP(hipHostMalloc(&c.pinned, c.pinned_cap, hipHostMallocDefault));
+    c.pin_in_cap = 1 << 20;
+    c.pin_in_off = 0;
+    TD_HIP(hipHostMalloc(&c.pin_in, c.pin_in_cap, hipHostMallocDefault));
     c.inited = true;
     c.err[0] = 0;
     return TD_OK;
@@ -339,6 +356,9 @@ void td_shutdown(void)
     c.n_ev = c.ev_next = c.n_pend = 0;
     if (c.pinned) (void)hipHostFree(c.pinned);
     c.pinned = nullptr;
+    if (c.pin_in) (void)hipHostFree(c.pin_in);
+    c.pin_in = nullptr;
+    c.pin_in_cap = c.pin_in_off = 0;
     if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
     c.own_stream = c.stream = nullptr;
     c.inited = false;

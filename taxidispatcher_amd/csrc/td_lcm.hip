@@ -626,10 +626,19 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
     }
     TD_HIP(hipGetLastError());
     TD_HIP(hipMemcpyAsync(c.pinned, c.lcm_d.p, sizeof(LcmOut), hipMemcpyDeviceToHost, c.stream));
+    // host outputs of a tick-sized model: the pair lists ride along into the pinned block (one round trip, no
+    // blocking pageable copies); d_rows and d_cols are contiguous (n entries each)
+    const bool via_pinned = !is_device_ptr(rows) && !is_device_ptr(cols) && (size_t)8192 + sizeof(int32_t) * 2 * (size_t)n <= c.pinned_cap;
+    if (via_pinned)
+        TD_HIP(hipMemcpyAsync((char *)c.pinned + 8192, d_rows, sizeof(int32_t) * 2 * (size_t)n, hipMemcpyDeviceToHost, c.stream));
     TD_HIP(hipStreamSynchronize(c.stream));
     LcmOut o = *(const LcmOut *)c.pinned;
     if (fast && o.last_min == INT_MAX) o.last_min = stop_value_on ? stop_value : mask;   // nothing left to look at
-    if (o.n_pairs > 0) {
+    if (o.n_pairs > 0 && via_pinned) {
+        const int32_t *hp = (const int32_t *)((const char *)c.pinned + 8192);
+        memcpy(rows, hp, sizeof(int32_t) * (size_t)o.n_pairs);
+        memcpy(cols, hp + n, sizeof(int32_t) * (size_t)o.n_pairs);
+    } else if (o.n_pairs > 0) {
         const hipMemcpyKind kr = is_device_ptr(rows) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
         const hipMemcpyKind kc = is_device_ptr(cols) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
         TD_HIP(hipMemcpyAsync(rows, d_rows, sizeof(int32_t) * (size_t)o.n_pairs, kr, c.stream));
