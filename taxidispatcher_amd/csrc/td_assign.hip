@@ -3111,6 +3111,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
             int mode = 0, kd = 0, accepted = 0, susp = 0;
             if ((rc = line_probe_wait(&mode, &kd, &susp))) return rc;
             early_check = susp != 0;
+            if (getenv("TD_DEBUG")) fprintf(stderr, "[td] line probe: n=%d verdict %d, %d constant rows, suspicious %d\n", n, mode, kd, susp);
             if (mode) {
                 const int32_t *res = nullptr;
                 bool line_t = false;
@@ -3122,6 +3123,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
                     const long long *unused = nullptr;
                     if ((rc = line_probe_launch(n, (const int32_t *)sv.tbuf.p, &unused))) return rc;
                     if ((rc = line_probe_wait(&mode, &kd))) return rc;
+                    if (getenv("TD_DEBUG")) fprintf(stderr, "[td] line probe on the transpose: verdict %d, %d constant rows\n", mode, kd);
                     line_t = true;
                 }
                 if (mode == 1 || mode == 3) {

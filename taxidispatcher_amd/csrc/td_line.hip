@@ -124,17 +124,39 @@ __global__ __launch_bounds__(1024) void k_line_probe(int n, const int32_t *__res
     if (cols_dummy) {
         // before the host pays for a transpose: columns 0 and 1 over the first 1024 ROWS must pass step 0 too
         // (a thresholded simulator model with dummy requests is refused here)
-        const long long wc = c[1];
-        const long long Ga = u0 + wc, Gb = labs64(u0 - wc);
-        int bad_c = 0, bad_d = 0;
-        if (t < n) {
-            const long long xx = c[(size_t)t * n], yy = c[(size_t)t * n + 1];
-            bad_c = !span_ok(xx, yy, Ga);
-            bad_d = !span_ok(xx, yy, Gb);
+        // Against column 0 the test takes a column that some row sees at ANOTHER distance (two requests on one
+        // stand are identical columns and would pass any such test): r = the first row with a real cell in
+        // column 0, c1 = the first of columns 1..64 that differs from column 0 in row r.
+        __shared__ int s_r, s_c1;
+        if (t == 0) {
+            s_r = INT_MAX;
+            s_c1 = 1;
         }
-        bad_c = __syncthreads_or(bad_c);
-        bad_d = __syncthreads_or(bad_d);
-        mode = (rows_dummy || (bad_c && bad_d)) ? 0 : 2;
+        __syncthreads();
+        if (t < n && c[(size_t)t * n] != B1) atomicMin(&s_r, t);
+        __syncthreads();
+        const int r = s_r;
+        int bad_c = 0, bad_d = 0;
+        if (r != INT_MAX) {
+            if (t < 64) {
+                const int j = 1 + t;
+                const unsigned long long dm = __ballot(j < n && c[(size_t)r * n + j] != c[(size_t)r * n]);
+                if (t == 0 && dm) s_c1 = 1 + (__ffsll((long long)dm) - 1);
+            }
+            __syncthreads();
+            const int c1 = s_c1;
+            const long long ur = c[(size_t)r * n], wr = c[(size_t)r * n + c1];
+            const long long Ga = ur + wr, Gb = labs64(ur - wr);
+            if (t < n) {
+                const long long xx = c[(size_t)t * n], yy = c[(size_t)t * n + c1];
+                bad_c = !span_ok(xx, yy, Ga);
+                bad_d = !span_ok(xx, yy, Gb);
+            }
+            bad_c = __syncthreads_or(bad_c);
+            bad_d = __syncthreads_or(bad_d);
+        }
+        const int real0 = r != INT_MAX;   // column 0 is a real request: not the fill value everywhere
+        mode = (rows_dummy || (bad_c && bad_d) || !real0) ? 0 : 2;
     } else if (!(bad_a && bad_b)) {
         ArgMax x;
         x.v = LLONG_MIN, x.i = 0x7fffffff;
