@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256) void k_lcms_minmax(int n, const int32_t *__res
         mx = max(mx, __shfl_xor(mx, o));
         cnt += __shfl_xor(cnt, o);
     }
-    // one set of atomics per workgroup (thousands of same-address atomics cost more than the scan)
+    // one partial per workgroup, reduced by the host with the read-back it does anyway (hundreds of same-address
+    // atomics cost ~30 ns each: more than the scan of a simulator-sized matrix)
     __shared__ int s_mn[4], s_mx[4];
     __shared__ long long s_cnt[4];
     const int w = threadIdx.x >> 6;
@@ -300,11 +301,12 @@ __global__ __launch_bounds__(256) void k_lcms_minmax(int n, const int32_t *__res
             mx = max(mx, s_mx[k]);
             cnt += s_cnt[k];
         }
-        if (cnt) {
-            atomicMin(&info->vmin, mn);
-            atomicMax(&info->vmax, mx);
-            atomicAdd((unsigned long long *)&info->count, (unsigned long long)cnt);
-        }
+        LcmsInfo part;
+        part.count = cnt;
+        part.vmin = mn;
+        part.vmax = mx;
+        part.pad[0] = part.pad[1] = 0;
+        info[blockIdx.x] = part;
     }
 }
 
@@ -337,6 +339,20 @@ __global__ __launch_bounds__(256) void k_lcms_rows(int n, const int32_t *__restr
             const int v = vv[u];
             int lv = (j < n && (int64_t)v <= hi) ? v - vmin : -1;
             unsigned long long act = __ballot(lv >= 0);
+            if (nlev <= 16) {
+                // few levels (a simulator model has 10): one ballot per level instead of a wave-wide minimum per level present
+                for (int l = 0; l < nlev && act; l++) {
+                    const unsigned long long m = __ballot(lv == l);
+                    if (!m) continue;
+                    if (SCATTER) {
+                        const int base = s_cnt[w][l];
+                        if (lv == l) cells[base + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)row << 16) | (uint32_t)j;
+                    }
+                    if (lane == 0) s_cnt[w][l] += __popcll(m);
+                    act &= ~m;
+                }
+                act = 0;
+            }
             while (act) {
                 // lowest level present among the still-active lanes (wave-uniform)
                 int cur = lv >= 0 ? lv : INT_MAX;
@@ -548,7 +564,7 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
     if ((rc = ensure(c.lcm_a, sizeof(unsigned long long) * (size_t)n))) return rc;
     if ((rc = ensure(c.lcm_b, sizeof(int32_t) * 2 * (size_t)n))) return rc;
     if ((rc = ensure(c.lcm_c, sizeof(int32_t) * (size_t)n))) return rc;
-    if ((rc = ensure(c.lcm_d, 256))) return rc;
+    if ((rc = ensure(c.lcm_d, 512 + sizeof(LcmsInfo) * (size_t)c.n_cu * 4))) return rc;
     const int pitch = ((n + 15) / 16) * 16;
     const bool narrow = n >= 128;   // below that a row is a single load per lane anyway
     if (narrow && (rc = ensure(c.cc, (size_t)n * pitch))) return rc;
@@ -563,23 +579,27 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
         // level lists: candidates are the cells the loop could ever take
         int64_t hi = std::min<int64_t>(cand_limit - 1, (int64_t)mask - 1);
         if (threshold >= 0) hi = std::min<int64_t>(hi, threshold);
-        LcmsInfo *d_info = (LcmsInfo *)((char *)c.lcm_d.p + 64);
-        LcmsInfo init;
-        init.count = 0;
-        init.vmin = INT_MAX;
-        init.vmax = INT_MIN;
-        init.pad[0] = init.pad[1] = 0;
+        const int64_t cellsN = (int64_t)n * n;
+        const int grid = (int)std::min<int64_t>((cellsN + 4095) / 4096, (int64_t)c.n_cu * 4);
+        LcmsInfo *d_info = (LcmsInfo *)((char *)c.lcm_d.p + 512);   // one partial per workgroup
         LcmsInfo info;
         {
             ProfScope ps(TD_K_LCM);
-            TD_HIP(hipMemcpyAsync(d_info, &init, sizeof(init), hipMemcpyHostToDevice, c.stream));
-            const int64_t cellsN = (int64_t)n * n;
-            const int grid = (int)std::min<int64_t>((cellsN + 4095) / 4096, (int64_t)c.n_cu * 4);
             k_lcms_minmax<<<grid, 256, 0, c.stream>>>(n, d_cost, hi, d_info);
         }
-        TD_HIP(hipMemcpyAsync(c.pinned, d_info, sizeof(LcmsInfo), hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipMemcpyAsync(c.pinned, d_info, sizeof(LcmsInfo) * (size_t)grid, hipMemcpyDeviceToHost, c.stream));
         TD_HIP(hipStreamSynchronize(c.stream));
-        info = *(const LcmsInfo *)c.pinned;
+        info.count = 0;
+        info.vmin = INT_MAX;
+        info.vmax = INT_MIN;
+        for (int g = 0; g < grid; g++) {
+            const LcmsInfo &pt = ((const LcmsInfo *)c.pinned)[g];
+            if (pt.count) {
+                info.count += pt.count;
+                info.vmin = std::min(info.vmin, pt.vmin);
+                info.vmax = std::max(info.vmax, pt.vmax);
+            }
+        }
         if (info.count > 0 && info.count <= (1ll << 28) && (int64_t)info.vmax - info.vmin < LV_MAX) {
             fast = true;
             const int nlev = info.vmax - info.vmin + 1;
