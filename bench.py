@@ -82,17 +82,19 @@ class TickWorkload:
 
     def step(self):
         td = self.td
-        td.cost_build(self.cab_to, self.dem_from, None, fill=250000, threshold=10, out=self.cost)
-        pairs, lm = td.LCM_simulator(self.cost, max_non_lcm=600)
-        rows = np.fromiter((p[0] for p in pairs), dtype=np.int64, count=len(pairs))
-        cols = np.fromiter((p[1] for p in pairs), dtype=np.int64, count=len(pairs))
-        keep_c = np.setdiff1d(np.arange(1300), rows)
-        keep_d = np.setdiff1d(np.arange(900), cols)
+        td.cost_build(self.cab_to, self.dem_from, None, fill=250000, threshold=10, out=self.cost, sync=False)
+        rows, cols, lm = td.LCM_simulator(self.cost, max_non_lcm=600, as_arrays=True)
+        mc = np.ones(1300, bool)
+        mc[rows] = False
+        md = np.ones(900, bool)
+        md[cols[cols < 900]] = False
+        keep_c = np.flatnonzero(mc)   # filter_out (simulate.py:64-69): the unmatched cabs / requests, in order
+        keep_d = np.flatnonzero(md)
         n2 = max(keep_c.size, keep_d.size)
         c2 = self.cost2[:n2 * n2].view(n2, n2)
-        td.cost_build(self.cab_to[keep_c], self.dem_from[keep_d], None, fill=250000, threshold=10, out=c2)
+        td.cost_build(self.cab_to[keep_c], self.dem_from[keep_d], None, fill=250000, threshold=10, out=c2, sync=False)
         r2c, total = td.assign(c2, n2)
-        self.last = (len(pairs), n2, total)
+        self.last = (len(rows), n2, total)
         return total
 
 

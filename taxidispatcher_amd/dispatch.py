@@ -64,9 +64,11 @@ def _dist_arg(distances):
 
 
 def cost_build(cab_to, dem_from, distances=None, fill=BIG_COST, threshold=-1, cab_id=None, dem_id=None,
-               by_id=False, out=None):
+               by_id=False, out=None, sync=True):
     """Thin wrapper over td_cost_build. Returns (n, cost) with cost an int32 n x n numpy array,
-    or writes into `out` (numpy array or torch CUDA tensor) and returns (n, out)."""
+    or writes into `out` (numpy array or torch CUDA tensor) and returns (n, out).
+    sync=False: a device `out` is NOT waited for — only for callers whose next use of it is another call of this
+    library (same stream, e.g. a tick loop: cost_build -> LCM -> assign)."""
     lib = _ffi.lib()
     cab_to = _ffi.as_i32(cab_to)
     dem_from = _ffi.as_i32(dem_from)
@@ -81,7 +83,7 @@ def cost_build(cab_to, dem_from, distances=None, fill=BIG_COST, threshold=-1, ca
         _ffi.check(lib.td_cost_build(_ffi.addr(cab_to), _ffi.addr(cab_id), n_s, _ffi.addr(dem_from),
                                      _ffi.addr(dem_id), n_d, dptr, S, int(fill), int(threshold), int(bool(by_id)),
                                      _ffi.addr(out)))
-        if getattr(out, "is_cuda", False):
+        if sync and getattr(out, "is_cuda", False):
             # device output: written asynchronously on the library's stream; torch works on its own
             _ffi.check(lib.td_synchronize())
     del keep
@@ -210,11 +212,14 @@ def LCM_heuristic(n, c):
     return total, list(map(int, rows)), list(map(int, cols))
 
 
-def LCM_simulator(cost, max_non_lcm=600, big_cost=BIG_COST):
-    """Simulator.java:523-549 -> (pairs [(cab, request)], LCM_min_val)."""
+def LCM_simulator(cost, max_non_lcm=600, big_cost=BIG_COST, as_arrays=False):
+    """Simulator.java:523-549 -> (pairs [(cab, request)], LCM_min_val); as_arrays=True: (rows, cols, LCM_min_val)
+    as int32 arrays (a tick loop that only indexes with them skips ~700 Python tuples per tick)."""
     cost_a = cost if hasattr(cost, "data_ptr") else _ffi.as_i32(cost)
     n = int(cost_a.shape[0])
     _, rows, cols, lm = _lcm(n, cost_a, big_cost, -1, 1, big_cost, max_non_lcm, big_cost)
+    if as_arrays:
+        return rows, cols, lm
     return list(zip(map(int, rows), map(int, cols))), lm
 
 
