@@ -255,7 +255,7 @@ __global__ __launch_bounds__(1024) void k_lcm_loop(int n, const int32_t *__restr
 //                   no live cell; survivors are exactly the cells the sequential greedy takes,
 //                   and they are emitted in list order.
 // =====================================================================================
-constexpr int LV_MAX = 64;
+constexpr int LV_MAX = 256;   // (pool-of-two costs are sums of three distances: up to ~150 levels on 50 stands)
 static int g_lcm_lists = getenv("TD_LCM_LISTS") ? atoi(getenv("TD_LCM_LISTS")) : 1;   // 0: always the row-scan loop
 
 struct LcmsInfo {
@@ -408,6 +408,9 @@ __global__ __launch_bounds__(1024) void k_lcms_scan(int total, int n, int nlev, 
     if (tid == 0) lvstart[nlev] = s_carry;
 }
 
+// SYM (pool of two, Simulator.java:729-739): a kept plan (A, B) takes BOTH customers out of both roles, i.e. one
+// "taken" set and one conflict table for rows and columns together.
+template <bool SYM>
 __global__ __launch_bounds__(1024) void k_lcms_greedy(int n, int hmask, int nlev, int vmin,
                                                       const uint32_t *__restrict__ cells,
                                                       const int *__restrict__ lvstart, int limit, int64_t sum_below,
@@ -420,10 +423,10 @@ __global__ __launch_bounds__(1024) void k_lcms_greedy(int n, int hmask, int nlev
     // The tables are indexed by (row & hmask) / (col & hmask): when n exceeds the table two rows can
     // share a slot, which only delays the later cell to the next pass (the test stays sufficient).
     int *rmin = reinterpret_cast<int *>(s_dyn);
-    int *cmin = rmin + (hmask + 1);
+    int *cmin = SYM ? rmin : rmin + (hmask + 1);
     const int nw32 = (n + 31) / 32;
-    uint32_t *rtk = reinterpret_cast<uint32_t *>(cmin + (hmask + 1));
-    uint32_t *ctk = rtk + nw32;
+    uint32_t *rtk = reinterpret_cast<uint32_t *>(rmin + 2 * (hmask + 1));
+    uint32_t *ctk = SYM ? rtk : rtk + nw32;
     __shared__ int s_w[16];
     __shared__ int s_any;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -443,12 +446,30 @@ __global__ __launch_bounds__(1024) void k_lcms_greedy(int n, int hmask, int nlev
     for (int lv = 0; lv < nlev && !done; lv++) {
         const int32_t val = vmin + lv;
         const int beg = lvstart[lv], end = lvstart[lv + 1];
-        for (int base = beg; base < end && !done; base += 1024) {
+        for (int sbase = beg; sbase < end && !done; sbase += 4096) {
+          // most of a long list is dead once the first picks are made: look at 4096 cells at a time first
+          // (one barrier), and only walk a 1024-cell chunk when something in the 4096 is still live
+          uint32_t rc4[4];
+          bool any4 = false;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+              const int i = sbase + q * 1024 + tid;
+              rc4[q] = i < end ? cells[i] : 0xFFFFFFFFu;
+              if (i < end) {
+                  const int r = (int)(rc4[q] >> 16), c = (int)(rc4[q] & 0xFFFFu);
+                  any4 |= !((rtk[r >> 5] >> (r & 31)) & 1u) && !((ctk[c >> 5] >> (c & 31)) & 1u);
+              }
+          }
+          if (!__syncthreads_or(any4)) continue;
+#pragma unroll 1
+          for (int q = 0; q < 4 && !done; q++) {
+            const int base = sbase + q * 1024;
+            if (base >= end) break;
             const int i = base + tid;
             int r = 0, c = 0;
             bool live = false;
             if (i < end) {
-                const uint32_t rc = cells[i];
+                const uint32_t rc = rc4[q];
                 r = (int)(rc >> 16);
                 c = (int)(rc & 0xFFFFu);
                 live = !((rtk[r >> 5] >> (r & 31)) & 1u) && !((ctk[c >> 5] >> (c & 31)) & 1u);
@@ -465,6 +486,7 @@ __global__ __launch_bounds__(1024) void k_lcms_greedy(int n, int hmask, int nlev
                 }
                 __syncthreads();
                 if (!s_any) break;
+                // (SYM: a cell whose two customers share a table slot would see its own second atomicMin: same tid, fine)
                 const bool win = live && rmin[hr] == tid && cmin[hc] == tid;
                 __syncthreads();
                 if (live) {   // reset only what was touched
@@ -502,6 +524,7 @@ __global__ __launch_bounds__(1024) void k_lcms_greedy(int n, int hmask, int nlev
             npairs += acc;
             if (npairs >= limit) done = true;
             __syncthreads();
+          }
         }
     }
     // Lists exhausted before the size limit: the reference's next look at the matrix decides
@@ -621,8 +644,8 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
             k_lcms_scan<<<1, 1024, 0, c.stream>>>(nlev * n, n, nlev, d_cnt, d_lvstart);
             k_lcms_rows<true><<<rgrid, 256, 0, c.stream>>>(n, d_cost, hi, info.vmin, nlev, d_cnt, (uint32_t *)c.cc.p);
             if (shm > 48 * 1024)
-                (void)hipFuncSetAttribute((const void *)k_lcms_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-            k_lcms_greedy<<<1, 1024, shm, c.stream>>>(n, hsz - 1, nlev, info.vmin, (const uint32_t *)c.cc.p, d_lvstart, limit,
+                (void)hipFuncSetAttribute((const void *)k_lcms_greedy<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            k_lcms_greedy<false><<<1, 1024, shm, c.stream>>>(n, hsz - 1, nlev, info.vmin, (const uint32_t *)c.cc.p, d_lvstart, limit,
                                                       sum_below, stop_value, d_rows, d_cols, (LcmOut *)c.lcm_d.p, d_exh, d_taken);
             k_lcms_lastmin<<<rgrid, 256, 0, c.stream>>>(n, d_cost, cand_limit, d_exh, d_taken, (LcmOut *)c.lcm_d.p);
         }
@@ -920,7 +943,7 @@ extern "C" int td_pool2(int n, const int32_t *from, const int32_t *to, const int
     if ((rc = ensure(c.lcm_a, sizeof(unsigned long long) * (size_t)n))) return rc;
     if ((rc = ensure(c.lcm_b, sizeof(int32_t) * 4 * (size_t)n))) return rc;
     if ((rc = ensure(c.lcm_c, sizeof(int32_t) * (size_t)n))) return rc;
-    if ((rc = ensure(c.lcm_d, 256))) return rc;
+    if ((rc = ensure(c.lcm_d, 512 + sizeof(LcmsInfo) * (size_t)c.n_cu * 4))) return rc;   // out, flags, min/max partials
     int32_t *pc = (int32_t *)c.stage_d.p;
     int32_t *d_a = (int32_t *)c.lcm_b.p, *d_b = d_a + n, *d_plan = d_a + 2 * n, *d_cost = d_a + 3 * n;
     const int pitch = ((n + 15) / 16) * 16;
@@ -936,6 +959,60 @@ extern "C" int td_pool2(int n, const int32_t *from, const int32_t *to, const int
             k_pool2_check<<<(n + 255) / 256, 256, 0, c.stream>>>(n, (const int32_t *)d_from, (const int32_t *)d_to, S, (int *)((char *)c.lcm_d.p + 192));
         dim3 g((n + 255) / 256, std::min(n, 1024));
         k_pool2_cost<<<g, 256, 0, c.stream>>>(n, (const int32_t *)d_from, (const int32_t *)d_to, (const int32_t *)d_dist, S, pc);
+    }
+    // The greedy pass over the n (n - 1) ordered pairs: level lists as in td_lcm (pair costs are sums of three
+    // distances: a few dozen to ~150 distinct values), walked by k_lcms_greedy<SYM>; the row-scan loop otherwise.
+    bool fast = false;
+    if (g_lcm_lists && n >= 64 && n <= 65536) {
+        const int64_t hi = (int64_t)INT_MAX - 1;
+        const int64_t cellsN = (int64_t)n * n;
+        const int grid = (int)std::min<int64_t>((cellsN + 4095) / 4096, (int64_t)c.n_cu * 4);
+        LcmsInfo *d_info = (LcmsInfo *)((char *)c.lcm_d.p + 512);
+        {
+            ProfScope ps(TD_K_LCM);
+            k_lcms_minmax<<<grid, 256, 0, c.stream>>>(n, pc, hi, d_info);
+        }
+        TD_HIP(hipMemcpyAsync(c.pinned, d_info, sizeof(LcmsInfo) * (size_t)grid, hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipStreamSynchronize(c.stream));
+        LcmsInfo info;
+        info.count = 0;
+        info.vmin = INT_MAX;
+        info.vmax = INT_MIN;
+        for (int g = 0; g < grid; g++) {
+            const LcmsInfo &pt = ((const LcmsInfo *)c.pinned)[g];
+            if (pt.count) {
+                info.count += pt.count;
+                info.vmin = std::min(info.vmin, pt.vmin);
+                info.vmax = std::max(info.vmax, pt.vmax);
+            }
+        }
+        if (info.count > 0 && info.count <= (1ll << 28) && (int64_t)info.vmax - info.vmin < LV_MAX) {
+            fast = true;
+            const int nlev = info.vmax - info.vmin + 1;
+            const int nw32 = (n + 31) / 32;
+            if ((rc = ensure(c.lcm_a, sizeof(int) * (size_t)nlev * n))) return rc;
+            if ((rc = ensure(c.cc, sizeof(uint32_t) * (size_t)info.count))) return rc;
+            if ((rc = ensure(c.lcm_c, sizeof(int) * (LV_MAX + 2) + sizeof(uint32_t) * 2 * (size_t)nw32 + 64))) return rc;
+            int *d_cnt = (int *)c.lcm_a.p;
+            int *d_lvstart = (int *)c.lcm_c.p;
+            uint32_t *d_taken = (uint32_t *)(d_lvstart + LV_MAX + 2);
+            int *d_exh = (int *)((char *)c.lcm_d.p + 96);
+            int hsz = 64;
+            while (hsz < n && hsz < 16384) hsz <<= 1;
+            const size_t shm = sizeof(int) * 2 * (size_t)hsz + sizeof(uint32_t) * 2 * (size_t)nw32;
+            ProfScope ps(TD_K_LCM);
+            const int rgrid = std::min((n + 3) / 4, c.n_cu * 8);
+            k_lcms_rows<false><<<rgrid, 256, 0, c.stream>>>(n, pc, hi, info.vmin, nlev, d_cnt, nullptr);
+            k_lcms_scan<<<1, 1024, 0, c.stream>>>(nlev * n, n, nlev, d_cnt, d_lvstart);
+            k_lcms_rows<true><<<rgrid, 256, 0, c.stream>>>(n, pc, hi, info.vmin, nlev, d_cnt, (uint32_t *)c.cc.p);
+            if (shm > 48 * 1024)
+                (void)hipFuncSetAttribute((const void *)k_lcms_greedy<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            k_lcms_greedy<true><<<1, 1024, shm, c.stream>>>(n, hsz - 1, nlev, info.vmin, (const uint32_t *)c.cc.p, d_lvstart, n / 2,
+                                                            (int64_t)INT64_MAX, 0, d_a, d_b, (LcmOut *)c.lcm_d.p, d_exh, d_taken);
+        }
+    }
+    if (!fast) {
+        ProfScope ps(TD_K_LCM);
         TD_HIP(hipMemsetD32Async((hipDeviceptr_t)d_base, INT_MAX, 1, c.stream));
         k_lcm_rowscan<<<std::min((n + 3) / 4, c.n_cu * 8), 256, 0, c.stream>>>(n, pc, cand_limit, (unsigned long long *)c.lcm_a.p, d_base);
         if (narrow) k_lcm_narrow<<<std::min(n, c.n_cu * 8), 256, 0, c.stream>>>(n, pitch, pc, cand_limit, d_base, (uint8_t *)c.cc.p);
