@@ -374,38 +374,49 @@ __global__ __launch_bounds__(256) void k_lcms_rows(int n, const int32_t *__restr
     }
 }
 
-// exclusive scan of rowcnt[nlev*n] in place (one workgroup), level starts to lvstart[nlev+1]
+// exclusive scan of rowcnt[nlev*n] in place (one workgroup), level starts to lvstart[nlev+1]; CH tiles of 1024 are
+// loaded before the serial chain of tile scans starts, so the chain does not wait on memory
 __global__ __launch_bounds__(1024) void k_lcms_scan(int total, int n, int nlev, int *__restrict__ a, int *__restrict__ lvstart)
 {
-    __shared__ int s_w[16];
-    __shared__ int s_carry;
+    constexpr int CH = 8;
+    __shared__ int s_w[2][16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < total; base += 1024) {
-        const int i = base + tid;
-        const int v = i < total ? a[i] : 0;
-        int incl = v;
+    int carry = 0, par = 0;
+    for (int base = 0; base < total; base += 1024 * CH) {
+        int v[CH];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
+        for (int u = 0; u < CH; u++) {
+            const int i = base + u * 1024 + tid;
+            v[u] = i < total ? a[i] : 0;
         }
-        if (lane == 63) s_w[w] = incl;
-        __syncthreads();
-        int wb = 0;
-        for (int k = 0; k < w; k++) wb += s_w[k];
-        const int carry = s_carry;
-        const int excl = carry + wb + incl - v;
-        if (i < total) {
-            a[i] = excl;
-            if (i % n == 0) lvstart[i / n] = excl;
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+            if (base + u * 1024 >= total) break;
+            int incl = v[u];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) s_w[par][w] = incl;
+            __syncthreads();
+            int wb = 0, all = 0;
+            for (int k = 0; k < 16; k++) {
+                const int x = s_w[par][k];
+                wb += (k < w) ? x : 0;
+                all += x;
+            }
+            par ^= 1;
+            const int i = base + u * 1024 + tid;
+            const int excl = carry + wb + incl - v[u];
+            if (i < total) {
+                a[i] = excl;
+                if (i % n == 0) lvstart[i / n] = excl;
+            }
+            carry += all;
         }
-        __syncthreads();
-        if (tid == 1023) s_carry = carry + wb + incl;
-        __syncthreads();
     }
-    if (tid == 0) lvstart[nlev] = s_carry;
+    if (tid == 0) lvstart[nlev] = carry;
 }
 
 // SYM (pool of two, Simulator.java:729-739): a kept plan (A, B) takes BOTH customers out of both roles, i.e. one
