@@ -11,7 +11,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 120
 cnt = bad = 0
 while time.time() < t_end:
-    kind = ["g1", "g4", "g2", "g3", "wide", "neg", "const", "rect"][int(rng.integers(0, 8))]
+    kind = ["g1", "g4", "g2", "g3", "wide", "neg", "const", "rect", "line", "lineu", "linep"][int(rng.integers(0, 11))]
     n = int(rng.integers(2, 1400)) if kind not in ("g2", "wide") else int(rng.integers(2, 700))
     if kind == "rect":   # padded rectangular model: constant rows / columns, sometimes permuted
         rr, rc = int(rng.integers(1, n + 1)), int(rng.integers(1, n + 1))
@@ -21,6 +21,18 @@ while time.time() < t_end:
             blk[rng.random(blk.shape) < 0.7] = 250000
         c[:rr, :rc] = blk
         if rng.random() < 0.3:
+            c = np.ascontiguousarray(c[rng.permutation(n)][:, rng.permutation(n)])
+    elif kind in ("line", "lineu", "linep"):
+        # line metric: balanced / padded with k missing cabs or requests / one cell perturbed
+        S = int(rng.choice([2, 3, 7, 50, 10 * n, 10**6]))
+        k = 0 if kind != "lineu" else int(rng.integers(1, min(40, n - 1) + 1)) if n > 2 else 0
+        nc, nr = (n - k, n) if rng.random() < 0.5 else (n, n - k)
+        a, b = rng.integers(0, S, nc), rng.integers(0, S, nr)
+        c = np.full((n, n), 250000, np.int32)
+        c[:nc, :nr] = np.abs(a[:, None] - b[None, :])
+        if kind == "linep":
+            c[int(rng.integers(0, n)), int(rng.integers(0, n))] = int(rng.integers(0, 3 * S + 5))
+        if rng.random() < 0.2:
             c = np.ascontiguousarray(c[rng.permutation(n)][:, rng.permutation(n)])
     else:
         c = make_instance(kind, n, rng)
