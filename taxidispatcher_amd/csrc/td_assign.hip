@@ -140,6 +140,7 @@ int g_speculate = 1;        // TD_SPECULATE     try u8 storage without waiting f
 int g_sap8 = 1;             // TD_SAP8          lean u8 finisher
 int g_psap8_batches = 1;    // TD_PSAP8         speculative batches of the lean u8 search
 int g_psap8_grid = 64;      // TD_PSAP8_GRID    searches per such batch
+int g_warm_tie_div = 2;     // TD_WARM_TIE_DIV  no warm start when more than n / this rows are tied at their minimum
 int g_wide_u16_n = 4096;    // TD_WIDE_U16_N    wide, tie-free 2-byte rows of n >= this are redone as 4-byte cells with 32-bit prices (0: never)
 bool g_line = true;         // TD_LINE          0: skip the line-metric recogniser (td_line.hip), always run the general solver
 int g_line_min_n = 2;       // TD_LINE_MIN_N    smallest n the recogniser is tried on
@@ -207,6 +208,7 @@ void read_tunables()
     if (const char *e = getenv("TD_SHAPE")) g_shape = atoi(e) != 0;
     if (const char *e = getenv("TD_SHAPE_MAX_N")) g_shape_max_n = atoi(e);
     if (const char *e = getenv("TD_WIDE_U16_N")) g_wide_u16_n = std::max(0, atoi(e));
+    if (const char *e = getenv("TD_WARM_TIE_DIV")) g_warm_tie_div = std::max(1, atoi(e));
     if (const char *e = getenv("TD_LINE")) g_line = atoi(e) != 0;
     if (const char *e = getenv("TD_LINE_MIN_N")) g_line_min_n = std::max(2, atoi(e));
     if (const char *e = getenv("TD_PSAP8_GRID")) g_psap8_grid = std::max(1, std::min(192, atoi(e)));
@@ -3225,7 +3227,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
             TD_HIP(hipMemcpyAsync(c.pinned, sv.misc.p, CTL_ALL * sizeof(int), hipMemcpyDeviceToHost, c.stream));
             TD_HIP(hipStreamSynchronize(c.stream));
             const int nfree_now = ((int *)c.pinned)[CTL_NFREE], tied0 = ((int *)c.pinned)[CTL_TIED];
-            wide = !(nfree_now < std::max(g_warm_minfree, n / 64) || (long long)tied0 * 16 * 8 > n);   // tied0 counts every 16th row
+            wide = !(nfree_now < std::max(g_warm_minfree, n / 64) || (long long)tied0 * 16 * g_warm_tie_div > n);   // tied0 counts every 16th row
             c.stats[2] = nfree_now;
         }
         if (wide && bpc == 2 && g_wide_u16_n && n >= g_wide_u16_n && g_narrow_price && !np_failed && known_range >= 0 &&

@@ -10,15 +10,25 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 120)
 cnt = bad = 0
 while time.time() < t_end:
-    kind = ["wide", "g2", "mid", "rect", "g1"][int(rng.integers(0, 5))]
-    n = int(rng.integers(8192, 12289))
+    kind = ["wide", "g2", "mid", "rect", "g1", "g2gen", "geo2", "g2u"][int(rng.integers(0, 8))]
+    n = int(rng.integers(4096, 12289))
+    td.set_line_metric(kind != "g2gen")   # g2gen: the general solver alone on the |a-b| geometry
     if kind == "wide":
         c = torch.randint(0, 10**6, (n, n), dtype=torch.int32, device="cuda")
     elif kind == "mid":     # u16 rows
         c = torch.randint(0, 40000, (n, n), dtype=torch.int32, device="cuda")
     elif kind == "g1":
         c = torch.randint(10, 41, (n, n), dtype=torch.int32, device="cuda")
-    elif kind == "g2":
+    elif kind == "geo2":    # 2-D Manhattan grid: 2-byte rows, wide and tie-free (redone as 4-byte cells for k_sapx)
+        ax, ay, bx, by = (torch.randint(0, 4000, (n,), device="cuda") for _ in range(4))
+        c = ((ax[:, None] - bx[None, :]).abs() + (ay[:, None] - by[None, :]).abs()).to(torch.int32).contiguous()
+    elif kind == "g2u":     # line metric with k missing cabs or requests
+        k = int(rng.integers(1, 40))
+        nc, nr = (n - k, n) if rng.random() < 0.5 else (n, n - k)
+        a = torch.randint(0, 10 * n, (nc,), device="cuda"); b = torch.randint(0, 10 * n, (nr,), device="cuda")
+        c = torch.full((n, n), 250000, dtype=torch.int32, device="cuda")
+        c[:nc, :nr] = (a[:, None] - b[None, :]).abs().to(torch.int32)
+    elif kind in ("g2", "g2gen"):
         a = torch.randint(0, 10 * n, (n,), device="cuda"); b = torch.randint(0, 10 * n, (n,), device="cuda")
         c = (a[:, None] - b[None, :]).abs().to(torch.int32).contiguous()
     else:
