@@ -876,7 +876,11 @@ __device__ __forceinline__ void shape_probe(int n, const int32_t *__restrict__ c
         const int ncol = atomicAdd(&sh[0], 0);
         const int nrow = ctl[CTL_NCONST];
         sh[1] = nrow;
-        if (ncol >= 16 && ncol * 16 >= n && ncol > 2 * nrow) {
+        // more constant columns than constant rows = more real rows than real columns: every surplus real row
+        // would need a search that scans all real columns before it reaches a dummy one (~30 us each, and too
+        // long a record for the speculative batches); in the transposed problem every real row finds a real column
+        const int margin = n / 256 > 32 ? n / 256 : 32;
+        if (ncol >= 16 && ncol - nrow >= margin) {
             sh[3] = 1;
             atomicOr(&ctl[CTL_FLAG], 4);
         }
