@@ -23,6 +23,8 @@ elif kind == "geo2":   # 2-D city grid, Manhattan distance (not in the reference
     side = int(os.environ.get("GEO_SIDE", "4000"))
     ax, ay, bx, by = (torch.from_numpy(rng.integers(0, side, n).astype(np.int32)).cuda() for _ in range(4))
     ct.copy_((ax[:, None] - bx[None, :]).abs() + (ay[:, None] - by[None, :]).abs())
+elif kind == "neg":     # uniform -5000..4999: 2-byte rows
+    ct.copy_(torch.from_numpy(rng.integers(-5000, 5000, (n, n)).astype(np.int32)))
 elif kind == "mid":     # uniform 0..40000: 2-byte rows, moderately tied
     ct.copy_(torch.randint(0, 40000, (n, n), dtype=torch.int32, device="cuda"))
 else:

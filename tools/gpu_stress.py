@@ -10,6 +10,7 @@ td.init(0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 120
 cnt = bad = 0
+slow = []
 while time.time() < t_end:
     kind = ["g1", "g4", "g2", "g3", "wide", "neg", "const", "rect", "line", "lineu", "linep"][int(rng.integers(0, 11))]
     n = int(rng.integers(2, 1400)) if kind not in ("g2", "wide") else int(rng.integers(2, 700))
@@ -36,7 +37,10 @@ while time.time() < t_end:
             c = np.ascontiguousarray(c[rng.permutation(n)][:, rng.permutation(n)])
     else:
         c = make_instance(kind, n, rng)
+    t0 = time.time()
     r2c, tot, dual = td.assign(c, want_dual=True)
+    dt = time.time() - t0
+    slow.append((dt / max(n, 1) ** 2, dt, kind, n, dict(td.last_stats())))
     ref = oracle.assign(c)[0]
     ok = tot == ref == dual and sorted(r2c.tolist()) == list(range(n)) and int(c[np.arange(n), r2c].astype(np.int64).sum()) == tot
     cnt += 1
@@ -44,3 +48,6 @@ while time.time() < t_end:
         bad += 1
         print("FAIL", kind, n, tot, ref, dual, td.last_stats(), flush=True)
 print("stress: %d instances, %d failures" % (cnt, bad))
+slow.sort(key=lambda x: -x[1])
+for x in slow[:12]:   # slowest per cell: where the solver spends unusually long
+    print("slow: %.2f ms %s n=%d %s" % (1e3 * x[1], x[2], x[3], x[4]))
