@@ -60,6 +60,8 @@ class HipShard:
         self.h = h
         self.device = torch.device("cuda", torch.cuda.current_device())
         self._opened = []
+        self._handle_cache = {}   # 64-byte hipIpc handle -> mapped pointer (rank 0: peers' compressed shards)
+        self.ipc_opens = 0
 
     def stream_ctx(self):
         """context in which solve_sharded issues its collectives and tensor ops"""
@@ -70,6 +72,7 @@ class HipShard:
         for p in self._opened:
             self.lib.td_ipc_close(ctypes.c_void_p(p))
         self._opened = []
+        self._handle_cache = {}
         if self.h:
             self.lib.td_shard_destroy(self.h)
             self.h = None
@@ -153,13 +156,21 @@ class HipShard:
         return self.torch.empty(self.n, dtype=self.torch.int32, device=self.device)
 
     def open_handle(self, handle_u8):
+        """Peer mapping of another rank's compressed shard.  A peer's workspace is grow-only, so across the solves of
+        one shard object its handle stays the same: the mapping is opened ONCE per distinct handle and reused
+        (hipIpcOpenMemHandle per solve costs a driver call per peer and leaves one more mapping open each time)."""
         raw = bytes(handle_u8[:64].cpu().numpy().tobytes())
+        cached = self._handle_cache.get(raw)
+        if cached is not None:
+            return cached
         buf = (ctypes.c_ubyte * 64).from_buffer_copy(raw)
         out = ctypes.c_void_p()
         rc = self.lib.td_ipc_open(buf, ctypes.byref(out))
         if rc != 0:
             return None
         self._opened.append(out.value)
+        self._handle_cache[raw] = out.value
+        self.ipc_opens += 1
         return out.value
 
     def cc_copy(self):
