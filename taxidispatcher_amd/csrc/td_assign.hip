@@ -134,7 +134,7 @@ int g_tie_evict = 1;        // TD_TIE_EVICT     rounds >= 1: a tie on owned colu
 int g_lds_rounds = 1;       // TD_LDS_ROUNDS    first rounds that stage the price vector in LDS
 int g_lds_grid = 1;         // TD_LDS_GRID      workgroups per CU of the LDS-staged bidding kernel
 int g_row_rounds = 2;       // TD_ROW_ROUNDS    from this round on: one workgroup per row (k_bid_row)
-int g_cgrid = 6;            // TD_CGRID         workgroups per CU of the compress pass
+int g_cgrid = 4;            // TD_CGRID         workgroups per CU of the compress pass
 int g_creg = 1;             // TD_CREG          register-resident compress kernel
 int g_speculate = 1;        // TD_SPECULATE     try u8 storage without waiting for the range flag
 int g_sap8 = 1;             // TD_SAP8          lean u8 finisher
