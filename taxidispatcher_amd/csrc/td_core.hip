@@ -482,6 +482,8 @@ static int cost_build_impl(const int32_t *cab_to, const int32_t *cab_id, int n_s
             const size_t shm = lds ? (size_t)S * S * 4 : 0;
             // rows per block column: enough workgroups to fill 256 CUs several times over
             int gx = (nq + 255) / 256;
+            // (more, shorter workgroups as in k_gen_uniform were measured: 231 -> 223 us at best, and the table-staging
+            // variant would stage its table more often)
             int gy = std::min(nrows, std::max(1, (c.n_cu * 16) / gx));
             dim3 g(gx, gy);
 #define TD_LAUNCH_CB(V, L)                                                                                            \
@@ -535,7 +537,9 @@ int td_gen_uniform(int n, uint64_t seed, int32_t lo, int32_t hi, int row0, int n
     const int nq = (n + 3) / 4;
     const bool vec = (n % 4 == 0) && (((uintptr_t)d_cost & 15) == 0);
     int gx = (nq + 255) / 256;
-    int gy = std::min(nrows, std::max(1, (c.n_cu * 16) / gx));
+    // workgroups per CU: many short workgroups (a few rows each) write faster than few long ones (16 -> 128: 218 -> 171 us at 16384^2)
+    static const int gen_wg_per_cu = getenv("TD_GEN_GRID") ? std::max(1, atoi(getenv("TD_GEN_GRID"))) : 128;
+    int gy = std::min(nrows, std::max(1, (c.n_cu * gen_wg_per_cu) / gx));
     dim3 g(gx, gy);
     {
         ProfScope ps(TD_K_GEN);
