@@ -165,6 +165,10 @@ int g_shape = 1;            // TD_SHAPE         probe for constant columns and s
 int g_shape_max_n = 1 << 20; // TD_SHAPE_MAX_N   largest n the probe runs for
 int g_narrow_price = 1;     // TD_NARROW_PRICE  4-byte cells with a row range <= 2^22: 32-bit prices and labels first (redone in 64 bits if a price reaches 2^27)
 long long g_np_plimit = NP_PLIMIT;   // TD_NP_PLIMIT  (tests) lower price limit of the narrow-price mode in k_assign / k_pcommit
+int g_forest = 1;           // TD_FOREST        cooperative incremental shortest-path forest (k_forest) as the finisher of 4-byte rows
+int g_forest_min_n = 2048;  // TD_FOREST_MIN_N  smallest n it is used for
+long long g_forest_w0 = 16; // TD_FOREST_W0     first label window
+long long g_forest_wx = 16; // TD_FOREST_WX     how far above the smallest free-column label a window may reach
 int g_solver_eps = 0;       // TD_SOLVER=eps    literal eps-scaling auction (comparison mode)
 int g_eps_theta = 8;        // TD_EPS_THETA
 long long g_eps0_mult = 4;  // TD_EPS0_MULT     eps0 = (n+1) * mult ; 0 = start at eps = 1
@@ -200,6 +204,10 @@ void read_tunables()
     if (const char *e = getenv("TD_LDS_GRID")) g_lds_grid = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("TD_NARROW_PRICE")) g_narrow_price = atoi(e) != 0;
     if (const char *e = getenv("TD_NP_PLIMIT")) g_np_plimit = std::max(1ll, std::min((long long)NP_PLIMIT, atoll(e)));
+    if (const char *e = getenv("TD_FOREST")) g_forest = atoi(e) != 0;
+    if (const char *e = getenv("TD_FOREST_MIN_N")) g_forest_min_n = std::max(64, atoi(e));
+    if (const char *e = getenv("TD_FOREST_W0")) g_forest_w0 = std::max(1ll, atoll(e));
+    if (const char *e = getenv("TD_FOREST_WX")) g_forest_wx = std::max(0ll, atoll(e));
     if (const char *e = getenv("TD_SOLVER")) g_solver_eps = (strcmp(e, "eps") == 0);
     if (const char *e = getenv("TD_EPS0_MULT")) g_eps0_mult = std::max(0ll, atoll(e));
     if (const char *e = getenv("TD_EPS_THETA")) g_eps_theta = std::max(2, atoi(e));
@@ -1962,6 +1970,8 @@ __global__ __launch_bounds__(TX * NG) void k_sapx(int n, int nchunks, const Shar
     }
 }
 
+#include "td_forest.h"
+
 // =====================================================================================
 // k_sap8: the finisher specialised for u8 rows / int32 prices with ONE 16-column chunk per
 // thread (n <= 16 384).  Same algorithm as k_sap; the step loop is cut to ~1/3 of the VALU
@@ -2497,7 +2507,7 @@ struct td_shard {
     int64_t fit_bound = -1;  // else: the limit of the narrowest width the rows have fitted so far
     int nchunks = 0, npad = 0;
     const int32_t *d_cost = nullptr;  // nrows x n, device
-    Buf stage, cc, price, owner, r2c, r2c_full, bid, pred, list, rowmin, rconst, misc, psrec, tbuf, xbuf;
+    Buf stage, cc, price, owner, r2c, r2c_full, bid, pred, list, rowmin, rconst, misc, psrec, tbuf, xbuf, fbuf;
     bool defer_const = false;  // constant rows sit out the solve and take the left-over columns (td_assign only)
     int nconst = -1;                 // constant rows counted by the last compress pass (-1: not read back)
     const int32_t *probe = nullptr;  // non-null for the one k_init_state launch that carries the shape probe
@@ -2505,7 +2515,7 @@ struct td_shard {
     const long long *skip = nullptr;  // device flag of a pending line-metric probe: non-zero makes the compress pass a no-op
     void free_all()
     {
-        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &rconst, &misc, &psrec, &tbuf, &xbuf};
+        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &rconst, &misc, &psrec, &tbuf, &xbuf, &fbuf};
         for (Buf *b : bs) {
             if (b->p) (void)hipFree(b->p);
             b->p = nullptr;
@@ -2693,6 +2703,54 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
     if (CH * E > 64) return fail(TD_ERANGE, "n=%d too large for the single-workgroup finisher", n);
     ProfScope ps(TD_K_SAP);
     k_freelist<<<1, 1024, 0, ctx().stream>>>(n, r2c_full, (int *)sv.list.p, (int *)sv.misc.p);
+    // ---- 4-byte rows of n >= TD_FOREST_MIN_N: the incremental shortest-path forest over all CUs (td_forest.h)
+    if constexpr (sizeof(CT) == 4) {
+        if (g_forest && n >= g_forest_min_n && n <= 32768 && tab.count == 1) {
+            Ctx &c = ctx();
+            using PT = typename Tr<CT>::PT;
+            typedef typename std::conditional<sizeof(PT) == 4, int, long long>::type LT;
+            const size_t off_base = (sizeof(FoShared) + 255) / 256 * 256;
+            const size_t off_root = off_base + sizeof(long long) * (size_t)n, off_col = off_root + sizeof(int) * (size_t)n;
+            const size_t off_pc = off_col + sizeof(int) * (size_t)n;
+            int rc = ensure(sv.fbuf, off_pc + sizeof(int) * (size_t)n);
+            if (rc) return rc;
+            FoShared *fs = (FoShared *)sv.fbuf.p;
+            long long *g_base = (long long *)((char *)sv.fbuf.p + off_base);
+            int *g_root = (int *)((char *)sv.fbuf.p + off_root), *g_col = (int *)((char *)sv.fbuf.p + off_col);
+            int *g_pcp = (int *)((char *)sv.fbuf.p + off_pc);
+            TD_HIP(hipMemsetAsync(fs, 0, offsetof(FoShared, board), c.stream));
+            k_forest_fill<<<(n + 255) / 256, 256, 0, c.stream>>>(n, g_base, g_root, g_col, g_pcp, (long long)FoLim<LT>::INF);
+            k_forest_init<CT><<<(n + 3) / 4, 256, 0, c.stream>>>(n, nchunks, tab, (const PT *)sv.price.p, (const int *)sv.list.p,
+                                                                (const int *)sv.misc.p, g_base, g_root, g_col);
+            int a_n = n, a_nch = nchunks, a_pcl = (n <= 16384) ? 1 : 0;
+            ShardTab a_tab = tab;
+            PT *a_pk = (PT *)sv.price.p;
+            int *a_owner = (int *)sv.owner.p, *a_r2c = r2c_full, *a_ctl = (int *)sv.misc.p;
+            long long a_w0 = g_forest_w0, a_wx = g_forest_wx;
+            void *kargs[] = {&a_n, &a_nch, &a_tab, &a_pk, &a_owner, &a_r2c, &g_pcp, &g_base, &g_root, &g_col, &a_ctl, &fs, &a_w0, &a_wx, &a_pcl};
+            const size_t dyn = std::max<size_t>(2 * (size_t)n, a_pcl ? 4 * (size_t)n : 0);
+            hipError_t le;
+            if (n <= 16384) {
+                (void)hipFuncSetAttribute((const void *)k_forest<CT, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+                le = hipLaunchCooperativeKernel((const void *)k_forest<CT, 64>, dim3((n + 63) / 64), dim3(FO_T), kargs, dyn, c.stream);
+            } else {
+                (void)hipFuncSetAttribute((const void *)k_forest<CT, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+                le = hipLaunchCooperativeKernel((const void *)k_forest<CT, 128>, dim3((n + 127) / 128), dim3(FO_T), kargs, dyn, c.stream);
+            }
+            if (le == hipSuccess) {
+                TD_HIP(hipGetLastError());
+                if (getenv("TD_DEBUG")) {
+                    long long st[16];
+                    TD_HIP(hipMemcpyAsync(st, (char *)fs + offsetof(FoShared, stat), sizeof(st), hipMemcpyDeviceToHost, c.stream));
+                    TD_HIP(hipStreamSynchronize(c.stream));
+                    fprintf(stderr, "[td] k_forest n=%d: levels %lld entries %lld ENDs %lld empty %lld repair rows %lld trees %lld | Mcycles wg0: select %lld barrier %lld board %lld relax %lld (main %lld comb %lld) END %lld (lpc %lld) repair %lld\n",
+                            n, st[0], st[1], st[2], st[3], st[4], st[5], st[8] >> 20, st[9] >> 20, st[10] >> 20, st[11] >> 20, st[6] >> 20, st[7] >> 20, st[12] >> 20, st[14] >> 20, st[13] >> 20);
+                }
+                return TD_OK;
+            }
+            (void)hipGetLastError();   // refused: the finishers below do the job
+        }
+    }
     // ---- speculative parallel searches first (a few batches), the serial workgroup mops up
     // (u8 instances go straight to the lean tie-batching serial workgroup, which is faster there)
     int nfree_left = -1;   // free rows the speculative batches left (-1: not read back)

@@ -1,0 +1,865 @@
+// td_forest.h — included by td_assign.hip (inside its anonymous namespace, after the finishers).
+//
+// k_forest: the finisher for wide, tie-free rows (4-byte cells: the |a-b| geometry, 2-D grids, uniform
+// 0..10^6) as ONE cooperative launch over all CUs — an INCREMENTAL shortest-path FOREST:
+//
+//   * every free row is a root, all trees grow at once under one common label scale (multi-source
+//     Dijkstra on the reduced costs c + p - u >= 0 that the eps = 0 bidding rounds leave);
+//   * workgroup g owns the columns [g*CW, (g+1)*CW): labels, predecessor COLUMN, tree ROOT, price, owner
+//     live in its LDS; nothing about a column is ever written by another workgroup;
+//   * a LEVEL = every workgroup publishes up to FO_CAP of its open columns (smallest labels first, inside
+//     a window W above the smallest open label of the previous level) + a header (smallest label that
+//     stayed open, smallest label of a free column) on a board in global memory, ONE grid barrier, then
+//     every workgroup relaxes its columns against all published rows.  Label-correcting: a column whose
+//     label drops after it was published is re-opened; labels below the end label are exact when no
+//     column is open below it (the argument of k_sapx / DESIGN.md §2);
+//   * END: a board without entries whose smallest open label is not below the smallest free-column label
+//     D.  Workgroup 0 flips the augmenting path of every tree that ends at D (predecessor columns in LDS),
+//     the trees are RELEASED at once (prices raised by D - label where the label is below D), the other
+//     trees stay; the columns that lose their label are repaired by relaxing them against the rows that
+//     are still in the forest;
+//   * a column whose TREE changes (re-parented at a lower or equal label) is "urgent": it is published
+//     whatever the window, and no END may happen while one is pending — at every END the root stored
+//     with a label is the root of its predecessor chain.
+//
+// tools/forest3_model.c is the CPU model of exactly this protocol (same board, gate, window and END
+// rules); it was used to validate exactness (dual == total, all reduced costs >= 0) before this ran.
+//
+// Inter-workgroup data (board, g_base / g_root / g_col, g_pc, owner, r2c) is written and read with
+// agent-scope relaxed atomics (sc1: L2-coherent, bypassing the per-CU L1) and ordered by the grid
+// barrier (monotonic counter, release / acquire fences at agent scope, bounded spin -> abort).
+
+constexpr int FO_CAP = 4;      // entries a workgroup publishes per level
+constexpr int FO_T = 256;      // threads per workgroup
+constexpr int FO_GMAX = 256;   // workgroups (one per CU)
+constexpr int FO_RELMAX = 16;  // trees released per END
+constexpr int FO_EMAX = FO_GMAX * FO_CAP;
+
+struct FoBoardWg {             // one 128-byte line per workgroup and parity
+    unsigned long long w[16];  // [0] minopen [1] minfree [2] end (col+1 | (root+1) << 20) [3] spare, [4 + 2i] base, [5 + 2i] packed entry
+};
+struct FoLine {                // one 128-byte line per counter: the pollers of one XCD do not disturb the others
+    unsigned long long v;
+    unsigned long long pad[15];
+};
+struct FoShared {
+    unsigned long long bar;    // start-up barrier (flat)
+    int abort;
+    int pad0;
+    long long stat[16];        // levels, entries, ENDs, empty levels, repair rows, released trees, spare, spare; cycles of workgroup 0: select, barrier, board, relax, END, repair
+    unsigned long long rel[4 + FO_RELMAX];   // [0] count [1] D (as bits) then the released roots
+    unsigned long long pad1[4];
+    FoLine xcnt[8];            // members of every XCD (counted at start-up)
+    FoLine xarr[8];            // arrivals per XCD
+    FoLine xgen[8];            // generation per XCD, set by the XCD's last arriver once every XCD has arrived
+    FoLine top;                // XCDs that have arrived
+    FoBoardWg board[2][FO_GMAX];
+};
+
+#define FO_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define FO_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+typedef unsigned int fo_v4u __attribute__((ext_vector_type(4)));
+typedef const fo_v4u __attribute__((address_space(1))) *fo_gvec;
+
+template <typename LT>
+struct FoLim {
+    static constexpr LT INF = sizeof(LT) == 4 ? (LT)(1 << 30) : (LT)((long long)1 << 60);
+    static constexpr LT WMAX = sizeof(LT) == 4 ? (LT)(1 << 26) : (LT)((long long)1 << 40);
+};
+
+// row duals of the free rows: base = -u, root = the row itself, no column
+template <typename CT>
+__global__ __launch_bounds__(256) void k_forest_init(int n, int nchunks, const ShardTab tab, const typename Tr<CT>::PT *__restrict__ pk,
+                                                     const int *__restrict__ list, const int *__restrict__ ctl, long long *g_base,
+                                                     int *g_root, int *g_col)
+{
+    using PT = typename Tr<CT>::PT;
+    typedef typename std::conditional<sizeof(PT) == 4, int, long long>::type LT;
+    constexpr int E = Tr<CT>::E;
+    if (ctl[CTL_FLAG]) return;
+    const int nfree = ctl[CTL_NFREE];
+    const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wv >= nfree) return;
+    const int f = list[wv];
+    const size_t pitch = (size_t)nchunks * E;
+    const CT *row = shard_row<CT>(tab, f, pitch);
+    LT m = FoLim<LT>::INF;
+    for (int ch = lane; ch < nchunks; ch += 64) {
+        const uint4 cv = *reinterpret_cast<const uint4 *>(row + (size_t)ch * E);
+        uint32_t c[E];
+        unpack<CT>(cv, c);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int j = ch * E + e;
+            if (j < n) {
+                const LT v = (LT)c[e] + (LT)(pk[j] >> 1);
+                m = v < m ? v : m;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const LT o = __shfl_xor(m, s);
+        m = o < m ? o : m;
+    }
+    if (lane == 0) {
+        g_base[f] = -(long long)m;
+        g_root[f] = f;
+        g_col[f] = -1;
+    }
+}
+
+__global__ void k_forest_fill(int n, long long *g_base, int *g_root, int *g_col, int *g_pc, long long inf)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        g_base[i] = inf;
+        g_root[i] = -1;
+        g_col[i] = -1;
+        g_pc[i] = -1;
+    }
+}
+
+// CW columns per workgroup (64 or 128), 4-byte cells only
+template <typename CT, int CW>
+__global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const ShardTab tab, typename Tr<CT>::PT *__restrict__ pk, int *owner_g,
+                                                 int *r2c_g, int *g_pc, long long *g_base, int *g_root, int *g_col,
+                                                 int *__restrict__ ctl, FoShared *sh, long long w0, long long wx, int pc_in_lds)
+{
+    using PT = typename Tr<CT>::PT;
+    typedef typename std::conditional<sizeof(PT) == 4, int, long long>::type LT;
+    static_assert(Tr<CT>::E == 4, "4-byte cells");
+    constexpr LT INF = FoLim<LT>::INF;
+    constexpr int SEGL = CW / 4;          // lanes per row segment (16 bytes each)
+    constexpr int NS = FO_T / SEGL;       // row slots relaxed at once
+    constexpr int NWV = FO_T / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fo_dyn[];   // predecessor columns (workgroup 0 at an END) / forest row list (repairs)
+    // ---- per-column state of this workgroup
+    __shared__ LT s_lab[CW], s_price[CW], s_cown[CW];
+    __shared__ int s_pc[CW], s_root[CW], s_own[CW];
+    __shared__ unsigned char s_inF[CW], s_dirty[CW], s_urgent[CW], s_need[CW];
+    // ---- entries of the level being relaxed
+    __shared__ LT s_ebase[FO_EMAX];
+    __shared__ int s_erow[FO_EMAX], s_eroot[FO_EMAX], s_ecol[FO_EMAX];
+    // ---- reductions
+    __shared__ LT s_rh[NS * CW];
+    __shared__ int s_rk[NS * CW];
+    __shared__ LT s_wk[NWV], s_wk2[NWV];
+    __shared__ int s_wj[NWV], s_wcnt[NWV + 1];
+    __shared__ int s_ok, s_any, s_tot;
+    __shared__ LT s_gd, s_gm;
+    __shared__ int s_rel[FO_RELMAX], s_nrel;
+    __shared__ LT s_hmf[FO_GMAX];
+    __shared__ unsigned long long s_he[FO_GMAX];
+
+    if (ctl[CTL_FLAG]) return;
+    int nfree = ctl[CTL_NFREE];
+    if (nfree <= 0) return;
+    const int G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t pitch = (size_t)nchunks * 4;
+    const CT *const cc0 = reinterpret_cast<const CT *>(tab.p[0]);   // one shard (host checks): no table lookup per row
+    const int j0 = wg * CW;
+    const bool colthr = tid < CW;
+    const int jc = j0 + tid;                       // the column of a column thread
+    const bool cvalid = colthr && jc < n;
+    unsigned long long epoch = 0;
+    // Grid barrier.  Every inter-workgroup word is written with an agent-scope (sc1, write-through) store and read with
+    // an agent-scope load, so no release / acquire fence is needed (MI355X_MICROARCH.md, hand-off table row 1): every
+    // storing wave drains its stores, the workgroup barrier orders them before ONE lane's atomic add, the consumers
+    // poll relaxed.  Bounded spin: a workgroup that waits too long raises `abort`, everybody leaves.
+    int xcc = 0, xmembers = 0, nxcd = 0;
+    auto grid_sync = [&]() __attribute__((always_inline)) -> bool {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            int ok = 1;
+            const unsigned long long e1 = epoch + 1ull;
+            const unsigned long long old = atomicAdd(&sh->xarr[xcc].v, 1ull);
+            if (old + 1ull == e1 * (unsigned long long)xmembers) {   // the last of this XCD
+                atomicAdd(&sh->top.v, 1ull);
+                const unsigned long long target = e1 * (unsigned long long)nxcd;
+                for (long long spins = 0;; spins++) {
+                    if (FO_LD(&sh->top.v) >= target) break;
+                    if (spins > 4000000ll || FO_LD(&sh->abort)) {
+                        FO_ST(&sh->abort, 1);
+                        ok = 0;
+                        break;
+                    }
+                }
+                FO_ST(&sh->xgen[xcc].v, e1);
+            } else {
+                for (long long spins = 0;; spins++) {
+                    if (FO_LD(&sh->xgen[xcc].v) >= e1) break;
+                    if (spins > 4000000ll || FO_LD(&sh->abort)) {
+                        FO_ST(&sh->abort, 1);
+                        ok = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            s_ok = ok;
+        }
+        epoch++;
+        __syncthreads();
+        return s_ok != 0;
+    };
+    {   // start-up: count the members of every XCD (placement is whatever the dispatcher did), one flat barrier
+        if (tid == 0) {
+            xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);   // HW_REG_XCC_ID[3:0]
+            atomicAdd(&sh->xcnt[xcc].v, 1ull);
+            atomicAdd(&sh->bar, 1ull);
+            int ok = 1;
+            for (long long spins = 0;; spins++) {
+                if (FO_LD(&sh->bar) >= (unsigned long long)G) break;
+                if (spins > 4000000ll || FO_LD(&sh->abort)) {
+                    FO_ST(&sh->abort, 1);
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            int nx = 0;
+            for (int q = 0; q < 8; q++) nx += FO_LD(&sh->xcnt[q].v) ? 1 : 0;
+            s_wj[0] = xcc;
+            s_wj[1] = (int)FO_LD(&sh->xcnt[xcc].v);
+            s_wj[2] = nx;
+            s_ok = ok;
+        }
+        __syncthreads();
+        xcc = s_wj[0];
+        xmembers = s_wj[1];
+        nxcd = s_wj[2];
+        if (!s_ok) return;
+        __syncthreads();
+    }
+    // ---- load the slice
+    if (colthr) {
+        LT pr = 0, co = 0;
+        int ow = -2;
+        if (cvalid) {
+            pr = (LT)(pk[jc] >> 1);
+            ow = owner_g[jc];
+            if (ow >= 0) co = (LT)(uint32_t)cc0[(size_t)ow * pitch + jc];
+        }
+        s_lab[tid] = INF;
+        s_price[tid] = pr;
+        s_cown[tid] = co;
+        s_pc[tid] = -1;
+        s_root[tid] = -1;
+        s_own[tid] = ow;
+        s_inF[tid] = 0;
+        s_dirty[tid] = 0;
+        s_urgent[tid] = 0;
+        s_need[tid] = 0;
+    }
+    __syncthreads();
+
+    // ---- relax this workgroup's columns against the M entries in s_e*
+    long long tr_main = 0, tr_comb = 0, te_lpc = 0, te_walk = 0;
+    auto relax = [&](int M, bool only_need) __attribute__((always_inline)) {
+        const long long ra = clock64();
+        const int seg = tid % SEGL, slot = tid / SEGL;
+        const int jb = j0 + seg * 4;
+        LT best[4];
+        int bk[4], mypc[4], myroot[4];
+        bool want = !only_need;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const int q = seg * 4 + x;
+            mypc[x] = s_pc[q];
+            myroot[x] = s_root[q];
+            best[x] = INF;
+            bk[x] = -1;
+            want = want || s_need[q];
+        }
+        const bool segok = jb < n && want;   // the columns >= n of the last segment are masked when the result is applied
+        constexpr int UNR = 8;
+        for (int k0 = slot; k0 < M; k0 += NS * UNR) {
+            uint4 cv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int k = min(k0 + u * NS, M - 1);
+                if (segok) {   // global address space: a generic (flat) load would also count on lgkmcnt and serialise with the LDS reads
+                    const fo_v4u t = *(fo_gvec)(uintptr_t)(cc0 + (size_t)s_erow[k] * pitch + jb);
+                    cv[u] = make_uint4(t.x, t.y, t.z, t.w);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int k = k0 + u * NS;
+                if (k < M && segok) {
+                    const LT b = s_ebase[k];
+                    const int ec = s_ecol[k], er = s_eroot[k];
+                    const uint32_t c[4] = {cv[u].x, cv[u].y, cv[u].z, cv[u].w};
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        const LT h = b + (LT)c[x];
+                        const bool same = (ec == mypc[x]) && (ec >= 0 || er == myroot[x]);
+                        if (h < best[x] || (h == best[x] && same)) {
+                            best[x] = h;
+                            bk[x] = k;
+                        }
+                    }
+                }
+            }
+        }
+        const long long rb = clock64();
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            s_rh[slot * CW + seg * 4 + x] = best[x];
+            s_rk[slot * CW + seg * 4 + x] = bk[x];
+        }
+        __syncthreads();
+        if (cvalid) {
+            LT b = INF;
+            int k = -1;
+            bool ksame = false;
+            const int pcj = s_pc[tid], rtj = s_root[tid];
+            for (int s = 0; s < NS; s++) {
+                const LT h = s_rh[s * CW + tid];
+                const int kk = s_rk[s * CW + tid];
+                if (kk < 0) continue;
+                const bool same = (s_ecol[kk] == pcj) && (s_ecol[kk] >= 0 || s_eroot[kk] == rtj);
+                if (h < b || (h == b && same && !ksame)) {
+                    b = h;
+                    k = kk;
+                    ksame = same;
+                }
+            }
+            if (k >= 0) {
+                const LT lb = s_lab[tid];
+                const LT tlj = (lb >= INF) ? INF : lb - s_price[tid];
+                const int ec = s_ecol[k], er = s_eroot[k];
+                if (b < tlj) {
+                    if (s_inF[tid]) {
+                        s_dirty[tid] = 1;
+                        if (rtj != er) s_urgent[tid] = 1;
+                    }
+                    s_lab[tid] = b + s_price[tid];
+                    s_pc[tid] = ec;
+                    s_root[tid] = er;
+                    FO_ST(&g_pc[jc], ec);
+                } else if (b == tlj && ec == pcj && (ec >= 0 || er == rtj) && rtj != er) {
+                    s_root[tid] = er;   // the predecessor moved to another tree at the same label
+                    if (s_inF[tid]) {
+                        s_dirty[tid] = 1;
+                        s_urgent[tid] = 1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (!only_need) {
+            tr_main += rb - ra;
+            tr_comb += clock64() - rb;
+        }
+    };
+
+    // ---- relax the slice against EVERY row of the forest (initial pass, repairs)
+    auto relax_all = [&]() __attribute__((always_inline)) -> long long {
+        unsigned short *flist = reinterpret_cast<unsigned short *>(fo_dyn);
+        // stage 1: compact the forest rows in row order (deterministic): every thread takes a contiguous block of
+        // rows, one block-wide exclusive scan of the counts
+        {
+            const int per = (n + FO_T - 1) / FO_T;   // <= 128 (n <= 32 768)
+            const int lo = tid * per;
+            unsigned long long m0 = 0, m1 = 0;
+            for (int r = 0; r < per; r++) {
+                const int i = lo + r;
+                const bool in = i < n && (LT)FO_LD(&g_base[i]) < INF;
+                if (in) {
+                    if (r < 64) m0 |= 1ull << r;
+                    else m1 |= 1ull << (r - 64);
+                }
+            }
+            const int cnt = __popcll(m0) + __popcll(m1);
+            int incl = cnt;
+#pragma unroll
+            for (int s2 = 1; s2 < 64; s2 <<= 1) {
+                const int v = __shfl_up(incl, s2);
+                if (lane >= s2) incl += v;
+            }
+            if (lane == 63) s_wcnt[wv] = incl;
+            __syncthreads();
+            int off = incl - cnt;
+            for (int q = 0; q < wv; q++) off += s_wcnt[q];
+            for (int r = 0; r < per; r++) {
+                const bool in = (r < 64) ? ((m0 >> r) & 1ull) : ((m1 >> (r - 64)) & 1ull);
+                if (in) flist[off++] = (unsigned short)(lo + r);
+            }
+            if (tid == FO_T - 1) s_tot = off;
+            __syncthreads();
+        }
+        const int F = s_tot;
+        for (int f0 = 0; f0 < F; f0 += FO_EMAX) {
+            const int M = min(FO_EMAX, F - f0);
+            for (int k = tid; k < M; k += FO_T) {
+                const int i = flist[f0 + k];
+                s_erow[k] = i;
+                s_ebase[k] = (LT)FO_LD(&g_base[i]);
+                s_eroot[k] = FO_LD(&g_root[i]);
+                s_ecol[k] = FO_LD(&g_col[i]);
+            }
+            __syncthreads();
+            relax(M, true);
+        }
+        return (long long)F;
+    };
+
+    // ---- block-wide argmin over the column threads: (flag desc, key asc, col asc)
+    auto block_argmin = [&](LT key, int col, LT &okey, int &ocol) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            const LT k2 = __shfl_xor(key, s);
+            const int c2 = __shfl_xor(col, s);
+            if (k2 < key || (k2 == key && c2 < col)) {
+                key = k2;
+                col = c2;
+            }
+        }
+        if (lane == 0) {
+            s_wk[wv] = key;
+            s_wj[wv] = col;
+        }
+        __syncthreads();
+        LT bk_ = s_wk[0];
+        int bc_ = s_wj[0];
+#pragma unroll
+        for (int q = 1; q < NWV; q++)
+            if (s_wk[q] < bk_ || (s_wk[q] == bk_ && s_wj[q] < bc_)) {
+                bk_ = s_wk[q];
+                bc_ = s_wj[q];
+            }
+        __syncthreads();
+        okey = bk_;
+        ocol = bc_;
+    };
+
+    long long tc_sel = 0, tc_bar = 0, tc_board = 0, tc_relax = 0, tc_end = 0, tc_rep = 0;
+    long long st_levels = 0, st_entries = 0, st_ends = 0, st_empty = 0, st_reprows = 0, st_trees = 0;
+    // ---- initial pass: every column against every free row
+    if (colthr) s_need[tid] = 1;
+    __syncthreads();
+    st_reprows += relax_all();
+    if (colthr) s_need[tid] = 0;
+    __syncthreads();
+    LT W = (LT)w0, gdlo = 0, gmfree = INF;
+    const LT WX = (LT)wx;
+    bool gate = false;
+    int par = 0;
+    bool bad = false;
+    const long long max_levels = 64ll * n + 4096;
+    for (long long it = 0; nfree > 0; it++) {
+        if (it > max_levels) {
+            bad = true;
+            break;
+        }
+        // ---------------- selection + header
+        const long long t0 = clock64();
+        LT thr = (gdlo >= INF) ? INF : (gdlo <= -INF ? -INF : (gdlo + W > INF ? INF : gdlo + W));
+        if (gmfree < INF && thr > gmfree + WX) thr = gmfree + WX;
+        FoBoardWg *mine = &sh->board[par][wg];
+        if constexpr (CW == 64) {
+            // one wave holds the whole slice: FO_CAP rounds of a wave argmin, no workgroup barrier inside
+            if (wv == 0) {
+                const LT NONE = INF + 1;
+                const LT lb = s_lab[lane];
+                const int ow = s_own[lane];
+                bool urg = s_urgent[lane] != 0;
+                bool isopen = cvalid && ow >= 0 && ((!s_inF[lane] && lb < INF) || (s_inF[lane] && s_dirty[lane]));
+                int npub = 0;
+                for (int r = 0; r < FO_CAP; r++) {
+                    LT key = NONE;
+                    if (isopen && urg) key = -INF - 1;
+                    else if (isopen && gate && lb < thr) key = lb;
+                    LT m = key;
+#pragma unroll
+                    for (int sx = 32; sx > 0; sx >>= 1) {
+                        const LT o = __shfl_xor(m, sx);
+                        m = o < m ? o : m;
+                    }
+                    if (m == NONE) break;
+                    const int L = __ffsll((long long)__ballot(key == m)) - 1;
+                    if (lane == L) {
+                        const LT base = lb - (s_cown[lane] + s_price[lane]);
+                        s_inF[lane] = 1;
+                        s_dirty[lane] = 0;
+                        s_urgent[lane] = 0;
+                        isopen = false;
+                        urg = false;
+                        FO_ST(&mine->w[4 + 2 * r], (unsigned long long)(long long)base);
+                        FO_ST(&mine->w[5 + 2 * r],
+                              (unsigned long long)(uint32_t)ow | ((unsigned long long)(uint32_t)(s_root[lane] + 1) << 20) | ((unsigned long long)(uint32_t)(jc + 1) << 40));
+                        FO_ST(&g_base[ow], (long long)base);
+                        FO_ST(&g_root[ow], s_root[lane]);
+                        FO_ST(&g_col[ow], jc);
+                    }
+                    npub++;
+                }
+                if (lane < FO_CAP && lane >= npub) FO_ST(&mine->w[5 + 2 * lane], ~0ull);
+                LT mo = isopen ? (urg ? -INF : lb) : INF;
+                const LT kf = (cvalid && ow == -1 && lb < INF) ? lb : INF;
+                LT mf = kf;
+#pragma unroll
+                for (int sx = 32; sx > 0; sx >>= 1) {
+                    const LT o1 = __shfl_xor(mo, sx), o2 = __shfl_xor(mf, sx);
+                    mo = o1 < mo ? o1 : mo;
+                    mf = o2 < mf ? o2 : mf;
+                }
+                const unsigned long long fb = __ballot(kf == mf && kf < INF);
+                const int cf = fb ? (__ffsll((long long)fb) - 1) : -1;
+                if (lane == 0) {
+                    FO_ST(&mine->w[0], (unsigned long long)(long long)mo);
+                    FO_ST(&mine->w[1], (unsigned long long)(long long)mf);
+                    unsigned long long e = 0;
+                    if (cf >= 0) e = (unsigned long long)(uint32_t)(j0 + cf + 1) | ((unsigned long long)(uint32_t)(s_root[cf] + 1) << 20);
+                    FO_ST(&mine->w[2], e);
+                }
+            }
+        } else {
+        int npub = 0;
+        for (int r = 0; r < FO_CAP; r++) {
+            LT key = INF + 1;   // nothing
+            int col = INT_MAX;
+            if (cvalid && s_own[tid] >= 0) {
+                const LT lb = s_lab[tid];
+                const bool open = (!s_inF[tid] && lb < INF) || (s_inF[tid] && s_dirty[tid]);
+                if (open && s_urgent[tid]) {
+                    key = -INF - 1;   // urgent columns first
+                    col = tid;
+                } else if (open && gate && lb < thr) {
+                    key = lb;
+                    col = tid;
+                }
+            }
+            LT k1;
+            int c1;
+            block_argmin(key, col, k1, c1);
+            if (c1 == INT_MAX) break;   // uniform
+            if (tid == c1) {
+                const LT lb = s_lab[tid];
+                const int row = s_own[tid];
+                const LT base = lb - (s_cown[tid] + s_price[tid]);
+                s_inF[tid] = 1;
+                s_dirty[tid] = 0;
+                s_urgent[tid] = 0;
+                FO_ST(&mine->w[4 + 2 * r], (unsigned long long)(long long)base);
+                FO_ST(&mine->w[5 + 2 * r],
+                      (unsigned long long)(uint32_t)row | ((unsigned long long)(uint32_t)(s_root[tid] + 1) << 20) | ((unsigned long long)(uint32_t)(jc + 1) << 40));
+                FO_ST(&g_base[row], (long long)base);
+                FO_ST(&g_root[row], s_root[tid]);
+                FO_ST(&g_col[row], jc);
+            }
+            npub++;
+            __syncthreads();
+        }
+        if (tid < FO_CAP && tid >= npub) FO_ST(&mine->w[5 + 2 * tid], ~0ull);
+        {   // header: smallest label that stayed open (-INF while an urgent column is unpublished), smallest free label + its column
+            LT ko = INF, kf = INF;
+            int cf = INT_MAX, co = INT_MAX;
+            if (cvalid) {
+                const LT lb = s_lab[tid];
+                if (s_own[tid] < 0) {
+                    if (s_own[tid] == -1 && lb < INF) {
+                        kf = lb;
+                        cf = tid;
+                    }
+                } else {
+                    const bool open = (!s_inF[tid] && lb < INF) || (s_inF[tid] && s_dirty[tid]);
+                    if (open) {
+                        ko = s_urgent[tid] ? -INF : lb;
+                        co = tid;
+                    }
+                }
+            }
+            LT mo, mf;
+            int c_o, c_f;
+            block_argmin(ko, co, mo, c_o);
+            block_argmin(kf, cf, mf, c_f);
+            if (tid == 0) {
+                FO_ST(&mine->w[0], (unsigned long long)(long long)mo);
+                FO_ST(&mine->w[1], (unsigned long long)(long long)mf);
+                unsigned long long e = 0;
+                if (c_f != INT_MAX) e = (unsigned long long)(uint32_t)(j0 + c_f + 1) | ((unsigned long long)(uint32_t)(s_root[c_f] + 1) << 20);
+                FO_ST(&mine->w[2], e);
+            }
+        }
+        }
+        const long long t1 = clock64();
+        if (!grid_sync()) {
+            bad = true;
+            break;
+        }
+        const long long t2 = clock64();
+        // ---------------- everybody reads the board
+        int mycnt = 0;
+        unsigned long long eb[FO_CAP], ep[FO_CAP];
+        LT hmo = INF, hmf = INF;
+        if (tid < G) {
+            const FoBoardWg *b = &sh->board[par][tid];
+            hmo = (LT)(long long)FO_LD(&b->w[0]);
+            hmf = (LT)(long long)FO_LD(&b->w[1]);
+            const unsigned long long he = FO_LD(&b->w[2]);
+#pragma unroll
+            for (int r = 0; r < FO_CAP; r++) {
+                eb[r] = FO_LD(&b->w[4 + 2 * r]);
+                ep[r] = FO_LD(&b->w[5 + 2 * r]);
+            }
+#pragma unroll
+            for (int r = 0; r < FO_CAP; r++) mycnt += (ep[r] != ~0ull) ? 1 : 0;
+            s_hmf[tid] = hmf;
+            s_he[tid] = he;
+        }
+        {
+            int incl = mycnt;
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const int v = __shfl_up(incl, s);
+                if (lane >= s) incl += v;
+            }
+            LT a = hmo, b2 = hmf;
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) {
+                const LT o1 = __shfl_xor(a, s), o2 = __shfl_xor(b2, s);
+                a = o1 < a ? o1 : a;
+                b2 = o2 < b2 ? o2 : b2;
+            }
+            if (lane == 63) s_wcnt[wv] = incl;
+            if (lane == 0) {
+                s_wk[wv] = a;
+                s_wk2[wv] = b2;
+            }
+            __syncthreads();
+            int off = incl - mycnt;
+            for (int q = 0; q < wv; q++) off += s_wcnt[q];
+            if (tid < G) {
+                int o = off;
+#pragma unroll
+                for (int r = 0; r < FO_CAP; r++)
+                    if (ep[r] != ~0ull) {
+                        s_ebase[o] = (LT)(long long)eb[r];
+                        s_erow[o] = (int)(ep[r] & 0xFFFFFu);
+                        s_eroot[o] = (int)((ep[r] >> 20) & 0xFFFFFu) - 1;
+                        s_ecol[o] = (int)((ep[r] >> 40) & 0xFFFFFu) - 1;
+                        o++;
+                    }
+            }
+            if (tid == 0) {
+                int t = 0;
+                LT x = INF, y = INF;
+                for (int q = 0; q < NWV; q++) {
+                    t += s_wcnt[q];
+                    x = s_wk[q] < x ? s_wk[q] : x;
+                    y = s_wk2[q] < y ? s_wk2[q] : y;
+                }
+                s_tot = t;
+                s_gd = x;
+                s_gm = y;
+            }
+            __syncthreads();
+        }
+        const int tot = s_tot;
+        const LT ndlo = s_gd, nmf = s_gm;
+        par ^= 1;
+        const long long t3 = clock64();
+        tc_sel += t1 - t0;
+        tc_bar += t2 - t1;
+        tc_board += t3 - t2;
+        if (tot > 0) {
+            st_levels++;
+            st_entries += tot;
+            relax(tot, false);
+            tc_relax += clock64() - t3;
+            if (tot < 32 && ndlo < nmf)
+                W = (W * 2 < FoLim<LT>::WMAX) ? W * 2 : W;
+            else if (tot > 256 && W > 1)
+                W /= 2;
+            gdlo = ndlo;
+            gmfree = nmf;
+            gate = gdlo < gmfree;
+            if (ndlo >= INF) {   // nothing stayed open: take what the relax just opened, up to WX above the free label
+                gdlo = nmf;
+                gate = true;
+            }
+            continue;
+        }
+        st_empty++;
+        if (ndlo < nmf) {   // the gate was closed and lower labels appeared
+            gdlo = ndlo;
+            gmfree = nmf;
+            gate = true;
+            continue;
+        }
+        if (nmf >= INF) {   // free rows but no path: cannot happen on a complete cost matrix
+            bad = true;
+            break;
+        }
+        // ---------------- END at D
+        st_ends++;
+        const LT D = nmf;
+        if (wg == 0) {
+            int *lpc = reinterpret_cast<int *>(fo_dyn);
+            const long long ea = clock64();
+            if (pc_in_lds) {
+                for (int i = tid; i < n; i += FO_T) lpc[i] = FO_LD(&g_pc[i]);
+            }
+            if (tid == 0) s_nrel = 0;
+            __syncthreads();
+            te_lpc += clock64() - ea;
+            // the ends: headers whose smallest free label is D, in workgroup order; one tree once
+            for (int q = 0; q < G; q++) {
+                const LT mf = s_hmf[q];
+                const unsigned long long e = s_he[q];
+                if (mf != D || e == 0) continue;   // uniform: every thread reads the same words
+                const int ecol = (int)(e & 0xFFFFFu) - 1, eroot = (int)((e >> 20) & 0xFFFFFu) - 1;
+                bool dup = false;
+                for (int k = 0; k < s_nrel; k++) dup = dup || (s_rel[k] == eroot);
+                if (dup || s_nrel >= FO_RELMAX || eroot < 0) continue;
+                // path: ecol, pc[ecol], ... ; its length by thread 0, then the flip in parallel
+                int *path = s_rk;   // NS * CW = 1024 ints; longer paths are flipped serially
+                if (tid == 0) {
+                    int len = 0, j = ecol;
+                    while (j >= 0 && len <= n) {
+                        if (len < NS * CW) path[len] = j;
+                        len++;
+                        j = pc_in_lds ? lpc[j] : FO_LD(&g_pc[j]);
+                    }
+                    s_any = len;
+                }
+                __syncthreads();
+                const int len = s_any;
+                if (len > n) {
+                    bad = true;   // a cycle: broken predecessor chain
+                } else if (len <= NS * CW) {
+                    int no[(NS * CW + FO_T - 1) / FO_T];
+#pragma unroll
+                    for (int u = 0; u < (NS * CW + FO_T - 1) / FO_T; u++) {
+                        const int k = tid + u * FO_T;
+                        no[u] = (k + 1 < len) ? FO_LD(&owner_g[path[k + 1]]) : eroot;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int u = 0; u < (NS * CW + FO_T - 1) / FO_T; u++) {
+                        const int k = tid + u * FO_T;
+                        if (k < len) {
+                            FO_ST(&owner_g[path[k]], no[u]);
+                            FO_ST(&r2c_g[no[u]], path[k]);
+                        }
+                    }
+                } else if (tid == 0) {
+                    int j = ecol;
+                    for (int hop = 0; hop <= n && j >= 0; hop++) {
+                        const int pj = pc_in_lds ? lpc[j] : FO_LD(&g_pc[j]);
+                        const int nr = (pj >= 0) ? FO_LD(&owner_g[pj]) : eroot;
+                        FO_ST(&owner_g[j], nr);
+                        FO_ST(&r2c_g[nr], j);
+                        j = pj;
+                    }
+                }
+                if (tid == 0) {
+                    FO_ST(&g_base[eroot], (long long)INF);
+                    s_rel[s_nrel] = eroot;
+                    s_nrel = s_nrel + 1;
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                FO_ST(&sh->rel[0], (unsigned long long)s_nrel);
+                FO_ST(&sh->rel[1], (unsigned long long)(long long)D);
+                for (int k = 0; k < s_nrel; k++) FO_ST(&sh->rel[4 + k], (unsigned long long)(uint32_t)s_rel[k]);
+            }
+        }
+        if (!grid_sync()) {
+            bad = true;
+            break;
+        }
+        // ---------------- release
+        if (tid == 0) s_nrel = (int)FO_LD(&sh->rel[0]);
+        if (tid < FO_RELMAX) s_rel[tid] = (int)FO_LD(&sh->rel[4 + tid]);
+        if (tid == 0) s_any = 0;
+        __syncthreads();
+        const int nrel = s_nrel;
+        if (nrel <= 0 || nrel > FO_RELMAX) {
+            bad = true;
+            FO_ST(&sh->abort, 1);
+        }
+        st_trees += nrel;
+        nfree -= nrel;
+        if (cvalid) {
+            bool hit = false;
+            const int rt = s_root[tid];
+            if (s_lab[tid] < INF)
+                for (int k = 0; k < nrel; k++) hit = hit || (rt == s_rel[k]);
+            if (hit) {
+                if (s_inF[tid]) {
+                    const LT lb = s_lab[tid];
+                    if (lb < D) {
+                        const LT np = s_price[tid] + (D - lb);
+                        s_price[tid] = np;
+                        if constexpr (IsNP<CT>::value) {
+                            if (np >= (LT)NP_PLIMIT) {
+                                atomicOr(&ctl[CTL_FLAG], 8);
+                                FO_ST(&sh->abort, 1);
+                            }
+                        }
+                    }
+                    FO_ST(&g_base[s_own[tid]], (long long)INF);
+                    s_inF[tid] = 0;
+                    s_dirty[tid] = 0;
+                    s_urgent[tid] = 0;
+                }
+                s_lab[tid] = INF;
+                s_pc[tid] = -1;
+                s_root[tid] = -1;
+                FO_ST(&g_pc[jc], -1);
+                s_need[tid] = 1;
+                s_any = 1;
+            }
+            const int no = FO_LD(&owner_g[jc]);
+            if (no != s_own[tid]) {   // a column of an augmenting path
+                s_own[tid] = no;
+                s_cown[tid] = (no >= 0) ? (LT)(uint32_t)cc0[(size_t)no * pitch + jc] : 0;
+            }
+        }
+        if (!grid_sync()) {   // g_base of the released rows is now visible everywhere
+            bad = true;
+            break;
+        }
+        const long long t4 = clock64();
+        if (s_any) {
+            st_reprows += relax_all();
+            if (colthr) s_need[tid] = 0;
+            __syncthreads();
+        }
+        tc_rep += clock64() - t4;
+        tc_end += t4 - t3;
+        gdlo = D;
+        gmfree = D;
+        gate = true;
+    }
+    if (bad) FO_ST(&sh->abort, 1);
+    // ---- write the prices back
+    if (cvalid) pk[jc] = (PT)((PT)s_price[tid] << 1) | (PT)1;
+    if (wg == 0 && tid == 0) {
+        ctl[CTL_NFREE] = nfree;
+        ctl[CTL_STEPS] = (int)(st_levels > INT_MAX ? INT_MAX : st_levels);
+        if (bad) atomicOr(&ctl[CTL_ERR], 32);
+        sh->stat[0] = st_levels;
+        sh->stat[1] = st_entries;
+        sh->stat[2] = st_ends;
+        sh->stat[3] = st_empty;
+        sh->stat[4] = st_reprows;
+        sh->stat[5] = st_trees;
+        sh->stat[8] = tc_sel;
+        sh->stat[9] = tc_bar;
+        sh->stat[10] = tc_board;
+        sh->stat[11] = tc_relax;
+        sh->stat[12] = tc_end;
+        sh->stat[13] = tc_rep;
+        sh->stat[6] = tr_main;
+        sh->stat[7] = tr_comb;
+        sh->stat[14] = te_lpc;
+    }
+}
