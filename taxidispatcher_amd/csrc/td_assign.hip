@@ -2710,9 +2710,10 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
             using PT = typename Tr<CT>::PT;
             typedef typename std::conditional<sizeof(PT) == 4, int, long long>::type LT;
             const size_t off_base = (sizeof(FoShared) + 255) / 256 * 256;
-            const size_t off_root = off_base + sizeof(long long) * (size_t)n, off_col = off_root + sizeof(int) * (size_t)n;
-            const size_t off_pc = off_col + sizeof(int) * (size_t)n;
-            int rc = ensure(sv.fbuf, off_pc + sizeof(int) * (size_t)n);
+            const size_t n4 = (size_t)(n + 3) / 4 * 4;   // the int arrays start 16-byte aligned and are padded (16-byte loads)
+            const size_t off_root = off_base + sizeof(long long) * n4, off_col = off_root + sizeof(int) * n4;
+            const size_t off_pc = off_col + sizeof(int) * n4;
+            int rc = ensure(sv.fbuf, off_pc + sizeof(int) * n4);
             if (rc) return rc;
             FoShared *fs = (FoShared *)sv.fbuf.p;
             long long *g_base = (long long *)((char *)sv.fbuf.p + off_base);
@@ -2728,23 +2729,32 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
             int *a_owner = (int *)sv.owner.p, *a_r2c = r2c_full, *a_ctl = (int *)sv.misc.p;
             long long a_w0 = g_forest_w0, a_wx = g_forest_wx;
             void *kargs[] = {&a_n, &a_nch, &a_tab, &a_pk, &a_owner, &a_r2c, &g_pcp, &g_base, &g_root, &g_col, &a_ctl, &fs, &a_w0, &a_wx, &a_pcl};
-            const size_t dyn = std::max<size_t>(2 * (size_t)n, a_pcl ? 4 * (size_t)n : 0);
+            const size_t dyn = std::max<size_t>(2 * n4, a_pcl ? 6 * n4 : 0);   // forest row list (u16) / predecessor columns + owners (u16) of workgroup 0 at an END
             hipError_t le;
-            if (n <= 16384) {
-                (void)hipFuncSetAttribute((const void *)k_forest<CT, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-                le = hipLaunchCooperativeKernel((const void *)k_forest<CT, 64>, dim3((n + 63) / 64), dim3(FO_T), kargs, dyn, c.stream);
+            static const int force_cw = getenv("TD_FOREST_CW") ? atoi(getenv("TD_FOREST_CW")) : 0;
+            static const int force_tb = getenv("TD_FOREST_TB") ? atoi(getenv("TD_FOREST_TB")) : 1024;
+#define TD_FO_LAUNCH(CWV, TBV)                                                                                                        \
+    do {                                                                                                                              \
+        (void)hipFuncSetAttribute((const void *)k_forest<CT, CWV, TBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);        \
+        le = hipLaunchCooperativeKernel((const void *)k_forest<CT, CWV, TBV>, dim3((n + CWV - 1) / CWV), dim3(TBV), kargs, dyn, c.stream); \
+    } while (0)
+            if (n <= 16384 && force_cw != 128) {
+                if (force_tb >= 1024) TD_FO_LAUNCH(64, 1024);
+                else if (force_tb >= 512) TD_FO_LAUNCH(64, 512);
+                else TD_FO_LAUNCH(64, 256);
             } else {
-                (void)hipFuncSetAttribute((const void *)k_forest<CT, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-                le = hipLaunchCooperativeKernel((const void *)k_forest<CT, 128>, dim3((n + 127) / 128), dim3(FO_T), kargs, dyn, c.stream);
+                if (force_tb >= 512) TD_FO_LAUNCH(128, 512);
+                else TD_FO_LAUNCH(128, 256);
             }
+#undef TD_FO_LAUNCH
             if (le == hipSuccess) {
                 TD_HIP(hipGetLastError());
                 if (getenv("TD_DEBUG")) {
                     long long st[16];
                     TD_HIP(hipMemcpyAsync(st, (char *)fs + offsetof(FoShared, stat), sizeof(st), hipMemcpyDeviceToHost, c.stream));
                     TD_HIP(hipStreamSynchronize(c.stream));
-                    fprintf(stderr, "[td] k_forest n=%d: levels %lld entries %lld ENDs %lld empty %lld repair rows %lld trees %lld | Mcycles wg0: select %lld barrier %lld board %lld relax %lld (main %lld comb %lld) END %lld (lpc %lld) repair %lld\n",
-                            n, st[0], st[1], st[2], st[3], st[4], st[5], st[8] >> 20, st[9] >> 20, st[10] >> 20, st[11] >> 20, st[6] >> 20, st[7] >> 20, st[12] >> 20, st[14] >> 20, st[13] >> 20);
+                    fprintf(stderr, "[td] k_forest n=%d: levels %lld entries %lld ENDs %lld empty %lld repair rows %lld (need cols wg0 %lld) trees %lld | Mcycles wg0: select %lld barrier %lld board %lld relax %lld (main %lld comb %lld) END %lld (lpc %lld) repair %lld\n",
+                            n, st[0], st[1], st[2], st[3], st[4], st[15], st[5], st[8] >> 20, st[9] >> 20, st[10] >> 20, st[11] >> 20, st[6] >> 20, st[7] >> 20, st[12] >> 20, st[14] >> 20, st[13] >> 20);
                 }
                 return TD_OK;
             }

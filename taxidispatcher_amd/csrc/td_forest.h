@@ -62,6 +62,13 @@ struct FoShared {
 typedef unsigned int fo_v4u __attribute__((ext_vector_type(4)));
 typedef const fo_v4u __attribute__((address_space(1))) *fo_gvec;
 
+// 16-byte agent-coherent (sc1) load through a buffer descriptor: base must be wave-uniform
+__device__ __forceinline__ fo_v4u fo_ld16(const void *base, uint32_t bytes, uint32_t byte_off)
+{
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16);
+}
+
 template <typename LT>
 struct FoLim {
     static constexpr LT INF = sizeof(LT) == 4 ? (LT)(1 << 30) : (LT)((long long)1 << 60);
@@ -122,8 +129,8 @@ __global__ void k_forest_fill(int n, long long *g_base, int *g_root, int *g_col,
 }
 
 // CW columns per workgroup (64 or 128), 4-byte cells only
-template <typename CT, int CW>
-__global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const ShardTab tab, typename Tr<CT>::PT *__restrict__ pk, int *owner_g,
+template <typename CT, int CW, int TB>
+__global__ __launch_bounds__(TB) void k_forest(int n, int nchunks, const ShardTab tab, typename Tr<CT>::PT *__restrict__ pk, int *owner_g,
                                                  int *r2c_g, int *g_pc, long long *g_base, int *g_root, int *g_col,
                                                  int *__restrict__ ctl, FoShared *sh, long long w0, long long wx, int pc_in_lds)
 {
@@ -132,8 +139,8 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
     static_assert(Tr<CT>::E == 4, "4-byte cells");
     constexpr LT INF = FoLim<LT>::INF;
     constexpr int SEGL = CW / 4;          // lanes per row segment (16 bytes each)
-    constexpr int NS = FO_T / SEGL;       // row slots relaxed at once
-    constexpr int NWV = FO_T / 64;
+    constexpr int NS = TB / SEGL;       // row slots relaxed at once
+    constexpr int NWV = TB / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char fo_dyn[];   // predecessor columns (workgroup 0 at an END) / forest row list (repairs)
     // ---- per-column state of this workgroup
     __shared__ LT s_lab[CW], s_price[CW], s_cown[CW];
@@ -143,11 +150,12 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
     __shared__ LT s_ebase[FO_EMAX];
     __shared__ int s_erow[FO_EMAX], s_eroot[FO_EMAX], s_ecol[FO_EMAX];
     // ---- reductions
-    __shared__ LT s_rh[NS * CW];
-    __shared__ int s_rk[NS * CW];
+    __shared__ LT s_rh[TB / 64 * CW];
+    __shared__ int s_rk[FO_EMAX];   // NWV * CW partial results of a relax; the path of an augmentation
     __shared__ LT s_wk[NWV], s_wk2[NWV];
     __shared__ int s_wj[NWV], s_wcnt[NWV + 1];
     __shared__ int s_ok, s_any, s_tot;
+    __shared__ int s_wflag[TB / 64];
     __shared__ LT s_gd, s_gm;
     __shared__ int s_rel[FO_RELMAX], s_nrel;
     __shared__ LT s_hmf[FO_GMAX];
@@ -159,7 +167,10 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
     const int G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t pitch = (size_t)nchunks * 4;
     const CT *const cc0 = reinterpret_cast<const CT *>(tab.p[0]);   // one shard (host checks): no table lookup per row
-    const int j0 = wg * CW;
+    // Workgroups are dealt round-robin over the 8 XCDs (observed, speed only): give every XCD a CONTIGUOUS range of
+    // column slices, so that the 32 CUs behind one L2 read one contiguous 8 KiB piece of every published row.
+    const int slice = (G % 8 == 0) ? (wg % 8) * (G / 8) + wg / 8 : wg;
+    const int j0 = slice * CW;
     const bool colthr = tid < CW;
     const int jc = j0 + tid;                       // the column of a column thread
     const bool cvalid = colthr && jc < n;
@@ -264,65 +275,117 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
         const int jb = j0 + seg * 4;
         LT best[4];
         int bk[4], mypc[4], myroot[4];
+        bool bs[4];
         bool want = !only_need;
 #pragma unroll
         for (int x = 0; x < 4; x++) {
             const int q = seg * 4 + x;
             mypc[x] = s_pc[q];
             myroot[x] = s_root[q];
-            best[x] = INF;
+            const LT lb = s_lab[q];
+            best[x] = (lb >= INF) ? INF : lb - s_price[q];   // only an improvement (or a tie) of the current label matters
             bk[x] = -1;
+            bs[x] = false;
             want = want || s_need[q];
         }
         const bool segok = jb < n && want;   // the columns >= n of the last segment are masked when the result is applied
-        constexpr int UNR = 8;
-        for (int k0 = slot; k0 < M; k0 += NS * UNR) {
-            uint4 cv[UNR];
+        constexpr int UNR = TB >= 1024 ? 4 : 8;
+        // one batch: UNR rows in flight per lane; the next batch is issued before this one is looked at
+        auto issue = [&](int k0, fo_v4u (&cv)[UNR]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < UNR; u++) {
                 const int k = min(k0 + u * NS, M - 1);
-                if (segok) {   // global address space: a generic (flat) load would also count on lgkmcnt and serialise with the LDS reads
-                    const fo_v4u t = *(fo_gvec)(uintptr_t)(cc0 + (size_t)s_erow[k] * pitch + jb);
-                    cv[u] = make_uint4(t.x, t.y, t.z, t.w);
-                }
+                cv[u] = *(fo_gvec)(uintptr_t)(cc0 + (size_t)s_erow[k] * pitch + jb);   // global address space: a flat load would wait on lgkmcnt too
             }
+        };
+        auto eat = [&](int k0, const fo_v4u (&cv)[UNR]) __attribute__((always_inline)) {
+            LT bb[UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; u++) {
-                const int k = k0 + u * NS;
-                if (k < M && segok) {
-                    const LT b = s_ebase[k];
-                    const int ec = s_ecol[k], er = s_eroot[k];
-                    const uint32_t c[4] = {cv[u].x, cv[u].y, cv[u].z, cv[u].w};
+            for (int u = 0; u < UNR; u++) bb[u] = (k0 + u * NS < M) ? s_ebase[k0 + u * NS] : INF;
 #pragma unroll
-                    for (int x = 0; x < 4; x++) {
-                        const LT h = b + (LT)c[x];
-                        const bool same = (ec == mypc[x]) && (ec >= 0 || er == myroot[x]);
-                        if (h < best[x] || (h == best[x] && same)) {
-                            best[x] = h;
-                            bk[x] = k;
+            for (int x = 0; x < 4; x++) {
+                LT m = INF;
+#pragma unroll
+                for (int u = 0; u < UNR; u++) {
+                    const LT h = bb[u] + (LT)cv[u][x];
+                    m = h < m ? h : m;
+                }
+                if (m <= best[x]) {   // rare once the labels have settled: which entry, and is it the column's own predecessor
+#pragma unroll
+                    for (int u = 0; u < UNR; u++) {
+                        const int k = k0 + u * NS;
+                        const LT h = bb[u] + (LT)cv[u][x];
+                        if (k < M && h <= best[x]) {
+                            const int ec = s_ecol[k], er = s_eroot[k];
+                            const bool same = (ec == mypc[x]) && (ec >= 0 || er == myroot[x]);
+                            if (h < best[x] || (same && !bs[x])) {
+                                best[x] = h;
+                                bk[x] = k;
+                                bs[x] = same;
+                            }
                         }
                     }
                 }
             }
+        };
+        if (segok) {
+            fo_v4u ca[UNR], cb[UNR];
+            int k0 = slot;
+            if (k0 < M) issue(k0, ca);
+            while (k0 < M) {
+                const int k1 = k0 + NS * UNR;
+                if (k1 < M) issue(k1, cb);
+                eat(k0, ca);
+                if (k1 >= M) break;
+                const int k2 = k1 + NS * UNR;
+                if (k2 < M) issue(k2, ca);
+                eat(k1, cb);
+                k0 = k2;
+            }
         }
         const long long rb = clock64();
+        // the slots of one wave first (lanes seg, seg + SEGL, ...), then the partial results of the waves that have any
+        // through LDS; total order of the candidates: smaller label, then the column's own predecessor, then the
+        // smaller entry index.  Late levels improve few labels: a wave without a candidate skips all of it.
+        const bool anyc = (bk[0] & bk[1] & bk[2] & bk[3]) >= 0;   // some bk >= 0 (all -1 gives -1)
+        const bool wany = __any(anyc);
+        if (wany) {
 #pragma unroll
-        for (int x = 0; x < 4; x++) {
-            s_rh[slot * CW + seg * 4 + x] = best[x];
-            s_rk[slot * CW + seg * 4 + x] = bk[x];
+            for (int sx = SEGL; sx < 64; sx <<= 1) {
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    const LT ob = __shfl_xor(best[x], sx);
+                    const int ok_ = __shfl_xor(bk[x], sx);
+                    const bool os = __shfl_xor((int)bs[x], sx) != 0;
+                    if (ob < best[x] || (ob == best[x] && ((os && !bs[x]) || (os == bs[x] && (unsigned)ok_ < (unsigned)bk[x])))) {
+                        best[x] = ob;
+                        bk[x] = ok_;
+                        bs[x] = os;
+                    }
+                }
+            }
+            if (lane < SEGL) {
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    s_rh[wv * CW + seg * 4 + x] = best[x];
+                    s_rk[wv * CW + seg * 4 + x] = bk[x];
+                }
+            }
         }
+        if (lane == 0) s_wflag[wv] = wany ? 1 : 0;
         __syncthreads();
         if (cvalid) {
             LT b = INF;
             int k = -1;
             bool ksame = false;
             const int pcj = s_pc[tid], rtj = s_root[tid];
-            for (int s = 0; s < NS; s++) {
-                const LT h = s_rh[s * CW + tid];
-                const int kk = s_rk[s * CW + tid];
+            for (int s2 = 0; s2 < NWV; s2++) {
+                if (!s_wflag[s2]) continue;
+                const LT h = s_rh[s2 * CW + tid];
+                const int kk = s_rk[s2 * CW + tid];
                 if (kk < 0) continue;
                 const bool same = (s_ecol[kk] == pcj) && (s_ecol[kk] >= 0 || s_eroot[kk] == rtj);
-                if (h < b || (h == b && same && !ksame)) {
+                if (k < 0 || h < b || (h == b && same && !ksame) || (h == b && same == ksame && kk < k)) {
                     b = h;
                     k = kk;
                     ksame = same;
@@ -363,7 +426,7 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
         // stage 1: compact the forest rows in row order (deterministic): every thread takes a contiguous block of
         // rows, one block-wide exclusive scan of the counts
         {
-            const int per = (n + FO_T - 1) / FO_T;   // <= 128 (n <= 32 768)
+            const int per = (n + TB - 1) / TB;   // <= 128 (n <= 32 768)
             const int lo = tid * per;
             unsigned long long m0 = 0, m1 = 0;
             for (int r = 0; r < per; r++) {
@@ -389,13 +452,13 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
                 const bool in = (r < 64) ? ((m0 >> r) & 1ull) : ((m1 >> (r - 64)) & 1ull);
                 if (in) flist[off++] = (unsigned short)(lo + r);
             }
-            if (tid == FO_T - 1) s_tot = off;
+            if (tid == TB - 1) s_tot = off;
             __syncthreads();
         }
         const int F = s_tot;
         for (int f0 = 0; f0 < F; f0 += FO_EMAX) {
             const int M = min(FO_EMAX, F - f0);
-            for (int k = tid; k < M; k += FO_T) {
+            for (int k = tid; k < M; k += TB) {
                 const int i = flist[f0 + k];
                 s_erow[k] = i;
                 s_ebase[k] = (LT)FO_LD(&g_base[i]);
@@ -438,7 +501,7 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
     };
 
     long long tc_sel = 0, tc_bar = 0, tc_board = 0, tc_relax = 0, tc_end = 0, tc_rep = 0;
-    long long st_levels = 0, st_entries = 0, st_ends = 0, st_empty = 0, st_reprows = 0, st_trees = 0;
+    long long st_levels = 0, st_entries = 0, st_ends = 0, st_empty = 0, st_reprows = 0, st_trees = 0, st_need = 0;
     // ---- initial pass: every column against every free row
     if (colthr) s_need[tid] = 1;
     __syncthreads();
@@ -447,7 +510,7 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
     __syncthreads();
     LT W = (LT)w0, gdlo = 0, gmfree = INF;
     const LT WX = (LT)wx;
-    bool gate = false;
+    bool gate = false, tight = false;
     int par = 0;
     bool bad = false;
     const long long max_levels = 64ll * n + 4096;
@@ -460,6 +523,7 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
         const long long t0 = clock64();
         LT thr = (gdlo >= INF) ? INF : (gdlo <= -INF ? -INF : (gdlo + W > INF ? INF : gdlo + W));
         if (gmfree < INF && thr > gmfree + WX) thr = gmfree + WX;
+        if (tight) thr = gmfree;   // nothing known to be open below the free label: take only what the last relax opened below it
         FoBoardWg *mine = &sh->board[par][wg];
         if constexpr (CW == 64) {
             // one wave holds the whole slice: FO_CAP rounds of a wave argmin, no workgroup barrier inside
@@ -598,14 +662,20 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
         unsigned long long eb[FO_CAP], ep[FO_CAP];
         LT hmo = INF, hmf = INF;
         if (tid < G) {
-            const FoBoardWg *b = &sh->board[par][tid];
-            hmo = (LT)(long long)FO_LD(&b->w[0]);
-            hmf = (LT)(long long)FO_LD(&b->w[1]);
-            const unsigned long long he = FO_LD(&b->w[2]);
+            const uint32_t boff = (uint32_t)tid * (uint32_t)sizeof(FoBoardWg);
+            const void *bb = &sh->board[par][0];
+            const fo_v4u q0 = fo_ld16(bb, sizeof(FoBoardWg) * FO_GMAX, boff);        // minopen, minfree
+            const fo_v4u q1 = fo_ld16(bb, sizeof(FoBoardWg) * FO_GMAX, boff + 16);   // end, spare
+            fo_v4u qe[FO_CAP];
+#pragma unroll
+            for (int r = 0; r < FO_CAP; r++) qe[r] = fo_ld16(bb, sizeof(FoBoardWg) * FO_GMAX, boff + 32 + 16 * r);
+            hmo = (LT)(long long)(((unsigned long long)q0.y << 32) | q0.x);
+            hmf = (LT)(long long)(((unsigned long long)q0.w << 32) | q0.z);
+            const unsigned long long he = ((unsigned long long)q1.y << 32) | q1.x;
 #pragma unroll
             for (int r = 0; r < FO_CAP; r++) {
-                eb[r] = FO_LD(&b->w[4 + 2 * r]);
-                ep[r] = FO_LD(&b->w[5 + 2 * r]);
+                eb[r] = ((unsigned long long)qe[r].y << 32) | qe[r].x;
+                ep[r] = ((unsigned long long)qe[r].w << 32) | qe[r].z;
             }
 #pragma unroll
             for (int r = 0; r < FO_CAP; r++) mycnt += (ep[r] != ~0ull) ? 1 : 0;
@@ -676,13 +746,14 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
                 W = (W * 2 < FoLim<LT>::WMAX) ? W * 2 : W;
             else if (tot > 256 && W > 1)
                 W /= 2;
+            // The minima are those of the columns that STAYED open; what the relax just opened is not in them.  So the
+            // gate stays open after a level with entries: when nothing is known to be open below the free label, the
+            // next selection takes exactly the labels below it (tight), and an empty board then IS the END.
             gdlo = ndlo;
             gmfree = nmf;
-            gate = gdlo < gmfree;
-            if (ndlo >= INF) {   // nothing stayed open: take what the relax just opened, up to WX above the free label
-                gdlo = nmf;
-                gate = true;
-            }
+            gate = true;
+            tight = !(ndlo < nmf) && nmf < INF;
+            if (ndlo >= INF) gdlo = nmf;
             continue;
         }
         st_empty++;
@@ -690,6 +761,7 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
             gdlo = ndlo;
             gmfree = nmf;
             gate = true;
+            tight = false;
             continue;
         }
         if (nmf >= INF) {   // free rows but no path: cannot happen on a complete cost matrix
@@ -700,75 +772,89 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
         st_ends++;
         const LT D = nmf;
         if (wg == 0) {
+            const int n4 = (n + 3) / 4;
             int *lpc = reinterpret_cast<int *>(fo_dyn);
+            unsigned short *lown = reinterpret_cast<unsigned short *>(fo_dyn + (size_t)n4 * 16);
             const long long ea = clock64();
-            if (pc_in_lds) {
-                for (int i = tid; i < n; i += FO_T) lpc[i] = FO_LD(&g_pc[i]);
+            if (pc_in_lds) {   // snapshots of the predecessor columns and of the owners (both arrays are padded to 4 ints)
+                for (int i = tid; i < n4; i += TB) {
+                    const fo_v4u t = fo_ld16(g_pc, (uint32_t)n4 * 16u, (uint32_t)i * 16u);
+                    *reinterpret_cast<fo_v4u *>(lpc + 4 * i) = t;
+                    const fo_v4u o = fo_ld16(owner_g, (uint32_t)n4 * 16u, (uint32_t)i * 16u);
+                    lown[4 * i + 0] = (unsigned short)o.x;
+                    lown[4 * i + 1] = (unsigned short)o.y;
+                    lown[4 * i + 2] = (unsigned short)o.z;
+                    lown[4 * i + 3] = (unsigned short)o.w;
+                }
             }
-            if (tid == 0) s_nrel = 0;
+            // the ends: headers whose smallest free label is D, in workgroup order
+            const bool isc = tid < G && s_hmf[tid] == D && s_he[tid] != 0;
+            const unsigned long long cb = __ballot(isc);
+            if (lane == 0) s_wcnt[wv] = __popcll(cb);
+            __syncthreads();
+            {
+                int off = 0;
+                for (int q = 0; q < wv; q++) off += s_wcnt[q];
+                if (isc) s_erow[off + __popcll(cb & ((1ull << lane) - 1ull))] = tid;   // s_e* is free between two levels
+            }
+            int ncand = 0;
+            for (int q = 0; q < NWV; q++) ncand += s_wcnt[q];
+            __syncthreads();
+            if (tid == 0) {   // one end per tree, at most FO_RELMAX trees (the others end at the next END, same D)
+                int nr = 0;
+                for (int ci = 0; ci < ncand && nr < FO_RELMAX; ci++) {
+                    const unsigned long long e = s_he[s_erow[ci]];
+                    const int ecol = (int)(e & 0xFFFFFu) - 1, eroot = (int)((e >> 20) & 0xFFFFFu) - 1;
+                    bool dup = eroot < 0;
+                    for (int k = 0; k < nr; k++) dup = dup || (s_rel[k] == eroot);
+                    if (dup) continue;
+                    s_rel[nr] = eroot;
+                    s_ecol[nr] = ecol;
+                    nr++;
+                }
+                s_nrel = nr;
+            }
             __syncthreads();
             te_lpc += clock64() - ea;
-            // the ends: headers whose smallest free label is D, in workgroup order; one tree once
-            for (int q = 0; q < G; q++) {
-                const LT mf = s_hmf[q];
-                const unsigned long long e = s_he[q];
-                if (mf != D || e == 0) continue;   // uniform: every thread reads the same words
-                const int ecol = (int)(e & 0xFFFFFu) - 1, eroot = (int)((e >> 20) & 0xFFFFFu) - 1;
-                bool dup = false;
-                for (int k = 0; k < s_nrel; k++) dup = dup || (s_rel[k] == eroot);
-                if (dup || s_nrel >= FO_RELMAX || eroot < 0) continue;
-                // path: ecol, pc[ecol], ... ; its length by thread 0, then the flip in parallel
-                int *path = s_rk;   // NS * CW = 1024 ints; longer paths are flipped serially
-                if (tid == 0) {
-                    int len = 0, j = ecol;
-                    while (j >= 0 && len <= n) {
-                        if (len < NS * CW) path[len] = j;
-                        len++;
-                        j = pc_in_lds ? lpc[j] : FO_LD(&g_pc[j]);
-                    }
-                    s_any = len;
-                }
-                __syncthreads();
-                const int len = s_any;
-                if (len > n) {
-                    bad = true;   // a cycle: broken predecessor chain
-                } else if (len <= NS * CW) {
-                    int no[(NS * CW + FO_T - 1) / FO_T];
-#pragma unroll
-                    for (int u = 0; u < (NS * CW + FO_T - 1) / FO_T; u++) {
-                        const int k = tid + u * FO_T;
-                        no[u] = (k + 1 < len) ? FO_LD(&owner_g[path[k + 1]]) : eroot;
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int u = 0; u < (NS * CW + FO_T - 1) / FO_T; u++) {
-                        const int k = tid + u * FO_T;
-                        if (k < len) {
-                            FO_ST(&owner_g[path[k]], no[u]);
-                            FO_ST(&r2c_g[no[u]], path[k]);
+            const int nr = s_nrel;
+            // the paths of different trees are vertex-disjoint: one lane walks and flips each of them, all at once
+            if (pc_in_lds) {
+                if (tid < nr) {
+                    const int r = s_rel[tid];
+                    int j = s_ecol[tid], hops = 0;
+                    while (j >= 0) {
+                        const int pj = lpc[j];
+                        const int nrow = (pj >= 0) ? (int)lown[pj] : r;   // the predecessor column's owner BEFORE the flip
+                        FO_ST(&owner_g[j], nrow);
+                        FO_ST(&r2c_g[nrow], j);
+                        j = pj;
+                        if (++hops > n) {   // a cycle: broken predecessor chain
+                            FO_ST(&sh->abort, 1);
+                            break;
                         }
                     }
-                } else if (tid == 0) {
-                    int j = ecol;
+                    FO_ST(&g_base[r], (long long)INF);
+                }
+            } else if (tid == 0) {
+                for (int t = 0; t < nr; t++) {
+                    const int r = s_rel[t];
+                    int j = s_ecol[t], prev_owner_of_pj = -1;
+                    // serial walk in global memory: read the predecessor and ITS owner before writing this column
                     for (int hop = 0; hop <= n && j >= 0; hop++) {
-                        const int pj = pc_in_lds ? lpc[j] : FO_LD(&g_pc[j]);
-                        const int nr = (pj >= 0) ? FO_LD(&owner_g[pj]) : eroot;
-                        FO_ST(&owner_g[j], nr);
-                        FO_ST(&r2c_g[nr], j);
+                        const int pj = FO_LD(&g_pc[j]);
+                        const int nrow = (pj >= 0) ? FO_LD(&owner_g[pj]) : r;
+                        FO_ST(&owner_g[j], nrow);
+                        FO_ST(&r2c_g[nrow], j);
                         j = pj;
                     }
+                    (void)prev_owner_of_pj;
+                    FO_ST(&g_base[r], (long long)INF);
                 }
-                if (tid == 0) {
-                    FO_ST(&g_base[eroot], (long long)INF);
-                    s_rel[s_nrel] = eroot;
-                    s_nrel = s_nrel + 1;
-                }
-                __syncthreads();
             }
             if (tid == 0) {
-                FO_ST(&sh->rel[0], (unsigned long long)s_nrel);
+                FO_ST(&sh->rel[0], (unsigned long long)nr);
                 FO_ST(&sh->rel[1], (unsigned long long)(long long)D);
-                for (int k = 0; k < s_nrel; k++) FO_ST(&sh->rel[4 + k], (unsigned long long)(uint32_t)s_rel[k]);
+                for (int k = 0; k < nr; k++) FO_ST(&sh->rel[4 + k], (unsigned long long)(uint32_t)s_rel[k]);
             }
         }
         if (!grid_sync()) {
@@ -778,7 +864,10 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
         // ---------------- release
         if (tid == 0) s_nrel = (int)FO_LD(&sh->rel[0]);
         if (tid < FO_RELMAX) s_rel[tid] = (int)FO_LD(&sh->rel[4 + tid]);
-        if (tid == 0) s_any = 0;
+        if (tid == 0) {
+            s_any = 0;
+            s_tot = 0;
+        }
         __syncthreads();
         const int nrel = s_nrel;
         if (nrel <= 0 || nrel > FO_RELMAX) {
@@ -816,6 +905,7 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
                 FO_ST(&g_pc[jc], -1);
                 s_need[tid] = 1;
                 s_any = 1;
+                atomicAdd(&s_tot, 1);
             }
             const int no = FO_LD(&owner_g[jc]);
             if (no != s_own[tid]) {   // a column of an augmenting path
@@ -827,6 +917,7 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
             bad = true;
             break;
         }
+        st_need += s_tot;
         const long long t4 = clock64();
         if (s_any) {
             st_reprows += relax_all();
@@ -838,6 +929,7 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
         gdlo = D;
         gmfree = D;
         gate = true;
+        tight = false;
     }
     if (bad) FO_ST(&sh->abort, 1);
     // ---- write the prices back
@@ -861,5 +953,6 @@ __global__ __launch_bounds__(FO_T) void k_forest(int n, int nchunks, const Shard
         sh->stat[6] = tr_main;
         sh->stat[7] = tr_comb;
         sh->stat[14] = te_lpc;
+        sh->stat[15] = st_need;
     }
 }

@@ -199,13 +199,14 @@ static void forest(LT W0)
 #pragma omp parallel for
     for (int w = 0; w < G; w++) relax_all(w);
     st_rowscans += nfree;
-    LT W = W0, gdlo = 0, gmfree = INF; int gate = 0;   /* first board: headers only */
+    LT W = W0, gdlo = 0, gmfree = INF; int gate = 0, tight = 0;   /* first board: headers only */
     long guard = 0;
     int32_t *path = malloc(4 * (n + 1)), *rl = malloc(4 * n), *oldown = malloc(4 * n);
     while (nfree > 0) {
         if (++guard > 64l * n + 1000) { fprintf(stderr, "level guard\n"); exit(8); }
         LT thr = (gdlo >= INF) ? INF : (gdlo <= -INF ? -INF : gdlo + W);
         { static LT WX = -1; if (WX < 0) WX = getenv("WX") ? atoll(getenv("WX")) : 16; if (gmfree < INF && thr > gmfree + WX) thr = gmfree + WX; }
+        if (tight) thr = gmfree;
         dbg_mfree = INF; for (int j = 0; j < n; j++) if (own[j] < 0 && lab[j] < dbg_mfree) dbg_mfree = lab[j];
         for (int w = 0; w < G; w++) select_wg(w, gate, thr, board + (size_t)w * CAP, hdr + w);
         /* ---- barrier; everybody reads the board */
@@ -222,12 +223,13 @@ static void forest(LT W0)
             if (tot < LO && ndlo < nmf) W = W * 2 < ((LT)1 << 40) ? W * 2 : W; else if (tot > HI && W > 1) W /= 2;
             /* minima of the columns that REMAINED open: what the relax just done opened is not in them.  With
              * nothing left open the next selection takes whatever opened below the smallest free label + W */
-            gdlo = ndlo; gmfree = nmf; gate = gdlo < gmfree;
-            if (ndlo >= INF) { gdlo = nmf; gate = 1; }
+            gdlo = ndlo; gmfree = nmf; gate = 1;
+            tight = !(ndlo < nmf) && nmf < INF;   /* nothing known open below the free label: take only what opened below it */
+            if (ndlo >= INF) gdlo = nmf;
             continue;
         }
         st_emptylv++;
-        if (ndlo < nmf) { gdlo = ndlo; gmfree = nmf; gate = 1; continue; }   /* gate was closed, work appeared */
+        if (ndlo < nmf) { gdlo = ndlo; gmfree = nmf; gate = 1; tight = 0; continue; }   /* gate was closed, work appeared */
         if (nmf >= INF) { fprintf(stderr, "no path (nfree=%d)\n", nfree); exit(3); }
         /* ---- END at D: workgroup 0 flips the paths */
         st_endsteps++;
@@ -263,7 +265,7 @@ static void forest(LT W0)
             int any = 0; for (int j = w * CW; j < (w + 1) * CW && j < n; j++) if (need[j]) { any = 1; need[j] = 0; }
             if (any) relax_all(w);
         }
-        gdlo = D; gmfree = D; gate = 1;   /* the next free label is not known yet: stay within WX of the last one */
+        gdlo = D; gmfree = D; gate = 1; tight = 0;   /* the next free label is not known yet: stay within WX of the last one */
         if (verbose) printf("   END D=%ld: %d trees, free=%d levels=%ld W=%ld\n", (long)D, nrl, nfree, st_levels, (long)W);
     }
     for (int j = 0; j < n; j++) p[j] = price[j];
