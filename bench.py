@@ -466,7 +466,7 @@ def main():
                 out = build_line({"error": "sharded leg did not finish within %.0f s (watchdog); replicas figure reported" % limit})
                 sys.stdout.flush()
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)   # non-zero on every rank: a hung collective must not read as success (the JSON line above carries the error)
 
         watchdog = threading.Timer(limit, bail)
         watchdog.daemon = True

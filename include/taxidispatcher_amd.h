@@ -141,6 +141,18 @@ TD_API int td_lcm_shard_create(int n, int row0, int nrows, const int32_t *cost_r
 TD_API int td_lcm_shard_destroy(td_lcm_shard *s);
 TD_API int td_lcm_shard_local_min(td_lcm_shard *s, int64_t *out3);
 TD_API int td_lcm_shard_take(td_lcm_shard *s, int row, int col);
+/* The same result in ROUNDS of locally dominant cells instead of one exchange per pick (Simulator.java:523-549 takes up
+ * to 700 picks per tick): a live cell that is the first minimum of its row AND of its column under the order (value, row,
+ * column) is taken by the sequential greedy before anything else of its row or column, so all of them are taken at once.
+ * Per round: round_colmin (per column the smallest live cell below `limit` of this shard's rows, key = (value << 32) | global
+ * row as a SIGNED int64, INT64_MAX = none) -> MIN all-reduce of the n keys -> round_apply (taken[c] = the key of a row whose
+ * first minimum is its column's minimum, INT64_MIN = none) -> MAX all-reduce -> round_commit (mask the taken columns
+ * everywhere, retire the taken rows, re-scan the rows that lost their cached column).  The picks sorted by (value, row, column)
+ * are td_lcm's pair list; the stop rules are applied to that order by the host driver (sharded.py lcm_sharded).  Vectors
+ * may be host or device memory. */
+TD_API int td_lcm_shard_round_colmin(td_lcm_shard *s, int64_t limit, int64_t *colmin);
+TD_API int td_lcm_shard_round_apply(td_lcm_shard *s, int64_t limit, const int64_t *colmin, int64_t *taken);
+TD_API int td_lcm_shard_round_commit(td_lcm_shard *s, const int64_t *taken);
 
 /* ---- f-3 pool of two (the step right before the path in every tick) -------------------
  * Replaces findPool: Simulator.java:681-758 (and pool.c:64-131): every ordered pair (A, B) of

@@ -122,7 +122,8 @@ enum {
     CTL_SHAPE = CTL_WORDS,
     CTL_PSTOP = CTL_WORDS + 6,
     CTL_TIED = CTL_WORDS + 7,    // rows whose two smallest costs are equal (bidding round 0, every 16th row sampled)   // a speculative batch committed nothing: later batches of the group exit at once
-    CTL_ALL = CTL_WORDS + 8
+    CTL_FOREST = CTL_WORDS + 8,  // levels of the incremental forest finisher (0: another finisher ran)
+    CTL_ALL = CTL_WORDS + 9
 };
 
 constexpr int ROW_BITS = 20;
@@ -3107,6 +3108,7 @@ int sv_readback(Solver &sv, int64_t *total, int64_t *dual, int max_rounds, int *
     c.stats[3] = hctl[CTL_STEPS];
     c.stats[4] = sv.bpc == 5 ? 4 : sv.bpc;   // bytes per stored cell (mode 5 = 4-byte cells with 32-bit prices)
     c.stats[5] = hctl[CTL_PACC];
+    c.stats[10] = hctl[CTL_FOREST];
     return TD_OK;
 }
 

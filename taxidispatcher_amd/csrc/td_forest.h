@@ -164,6 +164,7 @@ __global__ __launch_bounds__(TB) void k_forest(int n, int nchunks, const ShardTa
     if (ctl[CTL_FLAG]) return;
     int nfree = ctl[CTL_NFREE];
     if (nfree <= 0) return;
+    const int nfree0 = nfree;   // rows handed to the finisher (reported like the other finishers do)
     const int G = gridDim.x, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t pitch = (size_t)nchunks * 4;
     const CT *const cc0 = reinterpret_cast<const CT *>(tab.p[0]);   // one shard (host checks): no table lookup per row
@@ -935,8 +936,9 @@ __global__ __launch_bounds__(TB) void k_forest(int n, int nchunks, const ShardTa
     // ---- write the prices back
     if (cvalid) pk[jc] = (PT)((PT)s_price[tid] << 1) | (PT)1;
     if (wg == 0 && tid == 0) {
-        ctl[CTL_NFREE] = nfree;
+        ctl[CTL_NFREE] = bad ? nfree : nfree0;
         ctl[CTL_STEPS] = (int)(st_levels > INT_MAX ? INT_MAX : st_levels);
+        ctl[CTL_FOREST] = (int)(st_levels > INT_MAX ? INT_MAX : (st_levels > 0 ? st_levels : 1));
         if (bad) atomicOr(&ctl[CTL_ERR], 32);
         sh->stat[0] = st_levels;
         sh->stat[1] = st_entries;

@@ -779,7 +779,7 @@ struct td_lcm_shard {
     int n = 0, row0 = 0, nrows = 0;
     int64_t cand_limit = INT64_MAX;
     const int32_t *d_cost = nullptr;
-    Buf stage, rowbest, colmask, out;
+    Buf stage, rowbest, colmask, out, vec, vec2;
 };
 
 namespace {
@@ -850,6 +850,87 @@ __global__ __launch_bounds__(256) void k_lcmsh_rescan(int n, int nrows, int col,
     }
 }
 
+// ---- rounds of locally dominant cells --------------------------------------------
+// A live cell that is the first minimum of its row AND of its column under the reference's order (value, row,
+// column) is taken by the sequential greedy before anything else of its row or column, so ALL such cells can
+// be taken in one round; the rounds end when no candidate is left and the picks, sorted by that order, are the
+// sequential greedy's picks in its order.  Transport keys are SIGNED: (value << 32) | row, so a MIN / MAX
+// all-reduce of int64 vectors orders them like (value, row).
+constexpr long long LCMR_NONE_MIN = LLONG_MAX;   // column without a candidate (MIN all-reduce)
+constexpr long long LCMR_NONE_MAX = LLONG_MIN;   // column not taken in this round (MAX all-reduce)
+
+// colmin[c] = smallest (value, global row) over this shard's live rows, cells below `limit`, live columns
+__global__ __launch_bounds__(256) void k_lcmsh_colmin(int n, int nrows, int row0, const int32_t *__restrict__ cost, long long limit,
+                                                      const unsigned long long *__restrict__ rowbest,
+                                                      const uint32_t *__restrict__ colmask, long long *__restrict__ colmin)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    long long best = LCMR_NONE_MIN;
+    if (!((colmask[c >> 5] >> (c & 31)) & 1u)) {
+        for (int r = 0; r < nrows; r++) {
+            if (rowbest[r] == LCM_INF) continue;   // taken, or no candidate left in the row (uniform over the workgroup)
+            const int32_t v = cost[(int64_t)r * n + c];
+            if ((long long)v < limit) {
+                const long long k = ((long long)v << 32) | (long long)(uint32_t)(row0 + r);
+                best = k < best ? k : best;
+            }
+        }
+    }
+    colmin[c] = best;
+}
+
+// a row whose first minimum is also its column's minimum takes the column
+__global__ __launch_bounds__(256) void k_lcmsh_apply(int n, int nrows, int row0, long long limit,
+                                                     const unsigned long long *__restrict__ rowbest,
+                                                     const long long *__restrict__ colmin, long long *__restrict__ taken)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const unsigned long long k = rowbest[r];
+    if (k == LCM_INF) return;
+    const int32_t v = lcm_val(k);
+    if ((long long)v >= limit) return;
+    const int c = (int)(uint32_t)k;
+    const long long mine = ((long long)v << 32) | (long long)(uint32_t)(row0 + r);
+    if (colmin[c] == mine) taken[c] = mine;   // one writer per column: the column's minimum is unique
+}
+
+__global__ void k_lcmsh_fill64(int n, long long *p, long long v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// the round's picks (all shards): their columns are masked everywhere, their rows die on the owning shard
+__global__ __launch_bounds__(256) void k_lcmsh_commit(int n, int nrows, int row0, const long long *__restrict__ taken,
+                                                      unsigned long long *__restrict__ rowbest, uint32_t *__restrict__ colmask)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const long long t = taken[c];
+    if (t == LCMR_NONE_MAX) return;
+    atomicOr(&colmask[c >> 5], 1u << (c & 31));
+    const int r = (int)(uint32_t)t - row0;
+    if (r >= 0 && r < nrows) rowbest[r] = LCM_INF;
+}
+
+// rows whose cached first-minimum column has just been masked look for their next one
+__global__ __launch_bounds__(256) void k_lcmsh_rescan_masked(int n, int nrows, const int32_t *__restrict__ cost, int64_t cand_limit,
+                                                             unsigned long long *__restrict__ rowbest,
+                                                             const uint32_t *__restrict__ colmask)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int row = blockIdx.x * nw + w; row < nrows; row += gridDim.x * nw) {
+        const unsigned long long k = rowbest[row];
+        if (k == LCM_INF) continue;
+        const int cc = (int)(uint32_t)k;
+        if (!((colmask[cc >> 5] >> (cc & 31)) & 1u)) continue;
+        const unsigned long long b = lcm_scan_row(cost + (int64_t)row * n, n, lane, colmask, cand_limit);
+        if (lane == 0) rowbest[row] = b;
+    }
+}
+
 }  // namespace
 
 extern "C" int td_lcm_shard_create(int n, int row0, int nrows, const int32_t *cost_rows, int stop_value_on,
@@ -892,7 +973,7 @@ extern "C" int td_lcm_shard_destroy(td_lcm_shard *s)
     TD_REQUIRE_INIT();
     if (!s) return TD_OK;
     (void)hipStreamSynchronize(ctx().stream);
-    Buf *bs[] = {&s->stage, &s->rowbest, &s->colmask, &s->out};
+    Buf *bs[] = {&s->stage, &s->rowbest, &s->colmask, &s->out, &s->vec, &s->vec2};
     for (Buf *b : bs)
         if (b->p) (void)hipFree(b->p);
     delete s;
@@ -922,6 +1003,76 @@ extern "C" int td_lcm_shard_take(td_lcm_shard *s, int row, int col)
     if (s->nrows)
         k_lcmsh_rescan<<<std::max(1, std::min((s->nrows + 3) / 4, c.n_cu * 8)), 256, 0, c.stream>>>(
             s->n, s->nrows, col, s->d_cost, s->cand_limit, (unsigned long long *)s->rowbest.p, (const uint32_t *)s->colmask.p);
+    TD_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// ---- rounds of locally dominant cells: three calls per round, two exchanges of n int64 between them ----
+extern "C" int td_lcm_shard_round_colmin(td_lcm_shard *s, int64_t limit, int64_t *colmin)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (!s || !colmin) return fail(TD_EINVAL, "null argument");
+    const bool dev = is_device_ptr(colmin);
+    long long *d = (long long *)colmin;
+    if (!dev) {
+        int rc = ensure(s->vec, sizeof(long long) * (size_t)s->n);
+        if (rc) return rc;
+        d = (long long *)s->vec.p;
+    }
+    ProfScope ps(TD_K_LCM);
+    k_lcmsh_colmin<<<(s->n + 255) / 256, 256, 0, c.stream>>>(s->n, s->nrows, s->row0, s->d_cost, (long long)limit,
+                                                             (const unsigned long long *)s->rowbest.p, (const uint32_t *)s->colmask.p, d);
+    TD_HIP(hipGetLastError());
+    if (!dev) {
+        TD_HIP(hipMemcpyAsync(colmin, d, sizeof(long long) * (size_t)s->n, hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipStreamSynchronize(c.stream));
+    }
+    return TD_OK;
+}
+
+extern "C" int td_lcm_shard_round_apply(td_lcm_shard *s, int64_t limit, const int64_t *colmin, int64_t *taken)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (!s || !colmin || !taken) return fail(TD_EINVAL, "null argument");
+    const void *dcm = nullptr;
+    int rc = to_device(colmin, sizeof(long long) * (size_t)s->n, s->vec2, &dcm);
+    if (rc) return rc;
+    const bool dev = is_device_ptr(taken);
+    long long *d = (long long *)taken;
+    if (!dev) {
+        rc = ensure(s->vec, sizeof(long long) * (size_t)s->n);
+        if (rc) return rc;
+        d = (long long *)s->vec.p;
+    }
+    ProfScope ps(TD_K_LCM);
+    k_lcmsh_fill64<<<(s->n + 255) / 256, 256, 0, c.stream>>>(s->n, d, LCMR_NONE_MAX);
+    if (s->nrows)
+        k_lcmsh_apply<<<(s->nrows + 255) / 256, 256, 0, c.stream>>>(s->n, s->nrows, s->row0, (long long)limit,
+                                                                    (const unsigned long long *)s->rowbest.p, (const long long *)dcm, d);
+    TD_HIP(hipGetLastError());
+    if (!dev) {
+        TD_HIP(hipMemcpyAsync(taken, d, sizeof(long long) * (size_t)s->n, hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipStreamSynchronize(c.stream));
+    }
+    return TD_OK;
+}
+
+extern "C" int td_lcm_shard_round_commit(td_lcm_shard *s, const int64_t *taken)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (!s || !taken) return fail(TD_EINVAL, "null argument");
+    const void *dt = nullptr;
+    int rc = to_device(taken, sizeof(long long) * (size_t)s->n, s->vec2, &dt);
+    if (rc) return rc;
+    ProfScope ps(TD_K_LCM);
+    k_lcmsh_commit<<<(s->n + 255) / 256, 256, 0, c.stream>>>(s->n, s->nrows, s->row0, (const long long *)dt,
+                                                             (unsigned long long *)s->rowbest.p, (uint32_t *)s->colmask.p);
+    if (s->nrows)
+        k_lcmsh_rescan_masked<<<std::max(1, std::min((s->nrows + 3) / 4, c.n_cu * 8)), 256, 0, c.stream>>>(
+            s->n, s->nrows, s->d_cost, s->cand_limit, (unsigned long long *)s->rowbest.p, (const uint32_t *)s->colmask.p);
     TD_HIP(hipGetLastError());
     return TD_OK;
 }

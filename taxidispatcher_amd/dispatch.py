@@ -128,7 +128,7 @@ def last_stats():
     out = (ctypes.c_int64 * 16)()
     _ffi.check(_ffi.lib().td_last_stats(out, 16))
     d = {"bid_rounds": out[0], "warm_rounds": out[1], "sap_free_rows": out[2], "sap_steps": out[3], "bytes_per_cell": out[4],
-         "parallel_sap_rows": out[5], "narrow_price": out[6], "transposed": out[7], "line_metric": out[8], "line_dummies": out[9]}
+         "parallel_sap_rows": out[5], "narrow_price": out[6], "transposed": out[7], "line_metric": out[8], "line_dummies": out[9], "forest_levels": out[10]}
     return d
 
 

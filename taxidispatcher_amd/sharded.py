@@ -437,30 +437,141 @@ class HipLcmShard:
     def take(self, row, col):
         _ffi.check(self.lib.td_lcm_shard_take(self.h, int(row), int(col)))
 
+    # rounds of locally dominant cells: int64 vectors of length n on `device` (torch tensors)
+    device = "cuda"
+
+    def round_colmin(self, limit, out):
+        _ffi.check(self.lib.td_lcm_shard_round_colmin(self.h, int(limit), _ffi.addr(out)))
+        self._fence(out)
+
+    def round_apply(self, limit, colmin, out):
+        _ffi.check(self.lib.td_lcm_shard_round_apply(self.h, int(limit), _ffi.addr(colmin), _ffi.addr(out)))
+        self._fence(out)
+
+    @staticmethod
+    def _fence(t):
+        # the library queued the kernel that writes `t` on ITS stream; torch (element-wise min / max, the
+        # collective) reads it on its own: wait for the device before torch touches the vector
+        if getattr(t, "is_cuda", False):
+            import torch
+            torch.cuda.synchronize(t.device)
+
+    def round_commit(self, taken):
+        _ffi.check(self.lib.td_lcm_shard_round_commit(self.h, _ffi.addr(taken)))
+
     def close(self):
         if self.h:
             self.lib.td_lcm_shard_destroy(self.h)
             self.h = None
 
 
+LCM_NONE_MIN = 2**63 - 1     # round_colmin: column without a candidate
+LCM_NONE_MAX = -2**63        # round_apply: column not taken in this round
+
+
 def lcm_sharded(shards, dist, n, mask, threshold=-1, stop_value_on=0, stop_value=0, stop_size=-1, sum_below=INT64_MAX,
-                max_pairs=None):
+                max_pairs=None, by_pick=False, force_collectives=False):
     """The lowest-cost method over row shards, stop rules exactly as td_lcm / k_lcm_loop
-    (greedy_opt.py:61-82, heuristic.py:24-33, Simulator.java:523-549).  `shards`: the shard(s) this
-    rank owns (objects with local_min() -> (value, global row, col) and take(row, col)); `dist`:
-    torch.distributed or None for a single process.  One all-gather of 24 bytes per rank and pick.
+    (greedy_opt.py:61-82, heuristic.py:24-33, Simulator.java:523-549).  `shards`: the shard(s) this rank
+    owns; `dist`: torch.distributed or None for a single process.
+
+    ROUNDS of locally dominant cells: a live cell that is the first minimum of its row and
+    of its column under the reference's order (value, row, column) is taken by the sequential greedy before
+    anything else of its row or column, so every round takes all of them at once — two all-reduces of n
+    int64 keys per round (MIN of the column minima, MAX of the taken keys) and a few tens of rounds per
+    tick instead of one exchange per pick (~700).  The picks, sorted by the reference's order, ARE the
+    sequential greedy's picks in its order; the stop rules are then applied to that sequence.  The vectors
+    live on the shards' device, so the collectives run on whatever backend owns it (RCCL for HIP shards).
+    by_pick=True keeps the one-exchange-per-pick driver (shards with local_min / take only);
+    force_collectives=True issues the collectives with one rank too (a one-GPU test of the RCCL path).
     Returns (total, rows, cols, last_min), identical on every rank."""
+    if by_pick or not hasattr(shards[0], "round_colmin"):
+        return _lcm_sharded_by_pick(shards, dist, n, mask, threshold, stop_value_on, stop_value, stop_size, sum_below, max_pairs,
+                                    force_collectives)
     import torch
     world = dist.get_world_size() if dist is not None else 1
+    coll = dist is not None and (world > 1 or force_collectives)
+    dev = getattr(shards[0], "device", "cpu")
+    cand_limit = int(stop_value) if stop_value_on else LCM_NONE_MIN     # Simulator.java:529-537: cells >= big_cost are never looked at
+    limit = min(cand_limit, int(mask))                                   # only masked-valued cells remain -> stop
+    if threshold >= 0:
+        limit = min(limit, int(threshold) + 1)                           # greedy_opt.py:68-69: stop when the minimum is > threshold
+    colmin = torch.empty(n, dtype=torch.int64, device=dev)
+    taken = torch.empty(n, dtype=torch.int64, device=dev)
+    tmp = torch.empty(n, dtype=torch.int64, device=dev) if len(shards) > 1 else None
+    picked = torch.full((n,), LCM_NONE_MAX, dtype=torch.int64, device=dev)
+
+    def col_minima(lim):
+        shards[0].round_colmin(lim, colmin)
+        for sh in shards[1:]:
+            sh.round_colmin(lim, tmp)
+            torch.minimum(colmin, tmp, out=colmin)
+        if coll:
+            dist.all_reduce(colmin, op=dist.ReduceOp.MIN)
+
+    rounds = 0
+    while True:
+        col_minima(limit)
+        shards[0].round_apply(limit, colmin, taken)
+        for sh in shards[1:]:
+            sh.round_apply(limit, colmin, tmp)
+            torch.maximum(taken, tmp, out=taken)
+        if coll:
+            dist.all_reduce(taken, op=dist.ReduceOp.MAX)
+        if not bool((taken != LCM_NONE_MAX).any()):
+            break
+        rounds += 1
+        for sh in shards:
+            sh.round_commit(taken)
+        torch.maximum(picked, taken, out=picked)
+    keys = picked.cpu().numpy()
+    cols_all = np.nonzero(keys != LCM_NONE_MAX)[0]
+    vals = keys[cols_all] >> 32
+    rows_all = keys[cols_all] & 0xFFFFFFFF
+    order = np.lexsort((cols_all, rows_all, vals))      # the reference's order: value, then row, then column
+    iters = n if max_pairs is None else min(n, max_pairs)
+    pairs_r, pairs_c = [], []
+    total, size = 0, n
+    last_min = None
+    stopped = False
+    for k in order[:iters]:
+        v = int(vals[k])
+        last_min = v
+        pairs_r.append(int(rows_all[k]))
+        pairs_c.append(int(cols_all[k]))
+        if v < sum_below:
+            total += v
+        size -= 1
+        if stop_size >= 0 and size == stop_size:   # Simulator.java:544-545
+            stopped = True
+            break
+    if not stopped and len(pairs_r) < iters:
+        # the loop looks once more: the smallest live cell the scan still sees decides what last_min reads
+        col_minima(cand_limit)
+        m = int(colmin.min()) if n else LCM_NONE_MIN
+        last_min = (int(stop_value) if stop_value_on else int(mask)) if m == LCM_NONE_MIN else (m >> 32)
+    elif last_min is None:
+        last_min = int(stop_value)
+    lcm_sharded.last_rounds = rounds
+    return total, pairs_r, pairs_c, last_min
+
+
+def _lcm_sharded_by_pick(shards, dist, n, mask, threshold=-1, stop_value_on=0, stop_value=0, stop_size=-1, sum_below=INT64_MAX,
+                         max_pairs=None, force_collectives=False):
+    """One exchange per pick (the first sharded driver; kept as the comparator of the rounds)."""
+    import torch
+    world = dist.get_world_size() if dist is not None else 1
+    dev = getattr(shards[0], "device", "cpu")
     pairs_r, pairs_c = [], []
     total, size = 0, n
     last_min = stop_value
     iters = n if max_pairs is None else min(n, max_pairs)
     for _ in range(iters):
         best = min((s.local_min() for s in shards), default=(INT64_MAX, -1, -1))
-        if world > 1:
-            t = torch.tensor(best, dtype=torch.int64)
-            out = [torch.empty(3, dtype=torch.int64) for _ in range(world)]
+        if dist is not None and (world > 1 or force_collectives):
+            # on the shards' device: an RCCL-only process group has no backend for CPU tensors
+            t = torch.tensor(best, dtype=torch.int64, device=dev)
+            out = [torch.empty(3, dtype=torch.int64, device=dev) for _ in range(world)]
             dist.all_gather(out, t)
             best = min(tuple(int(x) for x in o.tolist()) for o in out)
         v, r, c = best

@@ -177,3 +177,41 @@ class ModelLcmShard:
         if self.row0 <= row < self.row0 + self.nrows:
             self.row_live[row - self.row0] = False
         self.col_live[col] = False
+
+    # ---- rounds of locally dominant cells (td_lcm_shard_round_*): torch int64 vectors on the CPU
+    device = "cpu"
+    NONE_MIN, NONE_MAX = 2**63 - 1, -2**63
+
+    def _row_first_min(self, i):
+        row = np.where(self.col_live, self.c[i], 2**62)
+        if self.limit is not None:
+            row = np.where(row < self.limit, row, 2**62)
+        j = int(np.argmin(row))
+        return (int(row[j]), j) if row[j] < 2**62 else None
+
+    def round_colmin(self, limit, out):
+        res = np.full(self.n, self.NONE_MIN, np.int64)
+        for i in np.nonzero(self.row_live)[0]:
+            if self._row_first_min(i) is None:      # no candidate left in the row: it sits out (like rowbest == INF)
+                continue
+            ok = self.col_live & (self.c[i] < limit)
+            keys = (self.c[i] << 32) | (self.row0 + int(i))
+            res = np.where(ok, np.minimum(res, keys), res)
+        out.copy_(__import__("torch").from_numpy(res))
+
+    def round_apply(self, limit, colmin, out):
+        cm = colmin.numpy()
+        res = np.full(self.n, self.NONE_MAX, np.int64)
+        for i in np.nonzero(self.row_live)[0]:
+            fm = self._row_first_min(i)
+            if fm is None or fm[0] >= limit:
+                continue
+            key = (fm[0] << 32) | (self.row0 + int(i))
+            if cm[fm[1]] == key:
+                res[fm[1]] = key
+        out.copy_(__import__("torch").from_numpy(res))
+
+    def round_commit(self, taken):
+        t = taken.numpy()
+        for c in np.nonzero(t != self.NONE_MAX)[0]:
+            self.take(int(t[c] & 0xFFFFFFFF), int(c))

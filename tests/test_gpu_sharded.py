@@ -149,10 +149,71 @@ def test_lcm_sharded_bit_identical_to_td_lcm(td):
                     shards.append(sharded.HipLcmShard(n, row0, nrows, np.ascontiguousarray(c[row0:row0 + nrows]),
                                                       kw.get("stop_value_on", 0), kw.get("stop_value", 0)))
                 tot, rows, cols, lm = sharded.lcm_sharded(shards, None, n, **kw)
+                rounds = sharded.lcm_sharded.last_rounds
             finally:
                 for s in shards:
                     s.close()
             assert tot == ref[0] and rows == ref[1].tolist() and cols == ref[2].tolist() and lm == ref[3], (n, world)
+            # rounds of locally dominant cells: tens of exchanges where the per-pick driver needs one per pair
+            assert rounds <= 64 and (len(rows) < 100 or rounds < len(rows) // 4), (rounds, len(rows))
+        # the one-exchange-per-pick driver (the round driver's comparator) on 3 shards
+        shards = []
+        try:
+            for r in range(3):
+                row0, nrows, _ = sharded.shard_bounds(n, 3, r)
+                shards.append(sharded.HipLcmShard(n, row0, nrows, np.ascontiguousarray(c[row0:row0 + nrows]),
+                                                  kw.get("stop_value_on", 0), kw.get("stop_value", 0)))
+            tot, rows, cols, lm = sharded.lcm_sharded(shards, None, n, by_pick=True, **kw)
+        finally:
+            for s in shards:
+                s.close()
+        assert tot == ref[0] and rows == ref[1].tolist() and cols == ref[2].tolist() and lm == ref[3], (n, "by pick")
+
+
+def _lcm_rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        import taxidispatcher_amd as td
+        from taxidispatcher_amd import dispatch, sharded
+        td.init(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        rng = np.random.default_rng(3)
+        a, b = rng.integers(0, 50, 700), rng.integers(0, 50, 500)
+        n, cost = td.cost_build(a, b, None, fill=250000, threshold=10)
+        kw = dict(mask=250000, stop_value_on=1, stop_value=250000, stop_size=300, sum_below=250000)
+        ref = dispatch._lcm(n, cost, kw["mask"], -1, 1, kw["stop_value"], kw["stop_size"], kw["sum_below"])
+        res = []
+        for by_pick in (False, True):
+            sh = sharded.HipLcmShard(n, 0, n, cost, 1, kw["stop_value"])
+            try:
+                tot, rows, cols, lm = sharded.lcm_sharded([sh], dist, n, by_pick=by_pick, force_collectives=True, **kw)
+            finally:
+                sh.close()
+            res.append(bool(tot == ref[0] and rows == ref[1].tolist() and cols == ref[2].tolist() and lm == ref[3]))
+        dist.destroy_process_group()
+        q.put(("ok", res))
+    except Exception as e:   # noqa: BLE001 — the parent asserts on the message
+        q.put(("error", repr(e)))
+
+
+@pytest.mark.gpu
+def test_lcm_sharded_through_rccl_one_rank(td):
+    """the sharded LCM's exchanges on an RCCL-only process group (backend nccl, one rank, collectives
+    forced): the key vectors are device tensors, so both drivers run where a CPU tensor would raise 'No backend type
+    associated with device type cpu'.  Own process: this one may already hold a gloo group."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_lcm_rccl_worker, args=(_free_port(), q))
+    p.start()
+    status, res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert status == "ok", res
+    assert res == [True, True]
 
 
 @pytest.mark.gpu
