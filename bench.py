@@ -65,8 +65,9 @@ def parse():
 
 class TickWorkload:
     """BASELINE configs[4]: the per-tick re-solve of Simulator.java:163-208 with LCM pre-reduce.
-    Cost matrices stay in HBM (torch tensors handed to the C ABI as device pointers); what crosses
-    PCIe per tick is the position arrays (<= 5 KiB), the LCM pair list and row_to_col."""
+    One C-ABI call per tick (td_tick): both cost matrices are library buffers in HBM, the shrink runs on the
+    device; what crosses PCIe per tick is the position arrays (<= 5 KiB), the LCM pair list, the kept indices
+    and row_to_col."""
 
     def __init__(self, seed, td):
         import torch
@@ -75,25 +76,13 @@ class TickWorkload:
         self.n = 1300
         self.cab_to = rng.integers(0, 50, 1300).astype(np.int32)
         self.dem_from = rng.integers(0, 50, 900).astype(np.int32)
-        self.cost = torch.empty((1300, 1300), dtype=torch.int32, device="cuda")
-        self.cost2 = torch.empty(1300 * 1300, dtype=torch.int32, device="cuda")
         self.expected = None
         self.kind = "tick"
 
     def step(self):
-        td = self.td
-        td.cost_build(self.cab_to, self.dem_from, None, fill=250000, threshold=10, out=self.cost, sync=False)
-        rows, cols, lm = td.LCM_simulator(self.cost, max_non_lcm=600, as_arrays=True)
-        mc = np.ones(1300, bool)
-        mc[rows] = False
-        md = np.ones(900, bool)
-        md[cols[cols < 900]] = False
-        keep_c = np.flatnonzero(mc)   # filter_out (simulate.py:64-69): the unmatched cabs / requests, in order
-        keep_d = np.flatnonzero(md)
-        n2 = max(keep_c.size, keep_d.size)
-        c2 = self.cost2[:n2 * n2].view(n2, n2)
-        td.cost_build(self.cab_to[keep_c], self.dem_from[keep_d], None, fill=250000, threshold=10, out=c2, sync=False)
-        r2c, total = td.assign(c2, n2)
+        # ONE C-ABI call: cost build -> LCM -> shrink on the device -> cost build -> assign (td_tick)
+        t = self.td.tick(self.cab_to, self.dem_from, None, big_cost=250000, drop_time=10, max_non_lcm=600)
+        rows, n2, total = t["lcm_rows"], t["n_rest"], t["total"]
         self.last = (len(rows), n2, total)
         return total
 

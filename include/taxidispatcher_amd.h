@@ -154,6 +154,24 @@ TD_API int td_lcm_shard_round_colmin(td_lcm_shard *s, int64_t limit, int64_t *co
 TD_API int td_lcm_shard_round_apply(td_lcm_shard *s, int64_t limit, const int64_t *colmin, int64_t *taken);
 TD_API int td_lcm_shard_round_commit(td_lcm_shard *s, const int64_t *taken);
 
+/* ---- one dispatcher tick in ONE call (BASELINE configs[4]) ---------------------------------
+ * Replaces, for one time step, Simulator.java:163-208 after createTempDemand / createTempSupply:
+ * calculate_cost (:493-520; simulate.py:17-33) -> LCM down to `stop_size` rows (:523-549, stops on big_cost or
+ * when MAX_NON_LCM rows are left; skipped when stop_size < 0 or >= n) -> removal of the matched cabs and requests
+ * (analyzePairs :613-674, filter_out greedy_opt.py:32-37 / simulate.py:64-69: a compaction kernel, the pair list
+ * never leaves the device for it) -> calculate_cost of the remainder -> optimal assignment (solver.py:26).
+ *   cab_to[n_s], dem_from[n_d], dist (S x S or NULL = |a-b|): host or device; fill = big_cost; threshold = DROP_TIME
+ *   (< 0: none).  Outputs (HOST arrays): the LCM pairs in the reference's order (capacity max(n_s, n_d)), *n_pairs,
+ *   *lcm_last_min (LCM_min_val, Simulator.java:188), kept_cabs / kept_dems (may be NULL: positions of the cabs /
+ *   requests left for the solver, in order), *n_rest = max of their counts, row_to_col[n_rest] and the total of
+ *   the remainder's optimal assignment (dummy cells count fill, like td_assign).  An empty model returns 0 pairs,
+ *   n_rest 0.  The cost matrices are library buffers in HBM (td_tick_release_workspace frees them). */
+TD_API int td_tick(const int32_t *cab_to, int n_s, const int32_t *dem_from, int n_d, const int32_t *dist, int S, int32_t fill,
+                   int32_t threshold, int stop_size, int32_t *lcm_rows, int32_t *lcm_cols, int32_t *n_pairs,
+                   int32_t *lcm_last_min, int32_t *kept_cabs, int32_t *kept_dems, int32_t *n_rest, int32_t *row_to_col,
+                   int64_t *total);
+TD_API void td_tick_release_workspace(void);
+
 /* ---- f-3 pool of two (the step right before the path in every tick) -------------------
  * Replaces findPool: Simulator.java:681-758 (and pool.c:64-131): every ordered pair (A, B) of
  * requests is a candidate with cost = min(plan1, plan2) (:693-717); plans are taken in STABLE

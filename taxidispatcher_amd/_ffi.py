@@ -45,6 +45,11 @@ SIGNATURES = {
     "td_lcm_shard_round_colmin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "td_lcm_shard_round_apply": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "td_lcm_shard_round_commit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "td_tick": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int32,
+                               ctypes.c_int32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32),
+                               ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32),
+                               ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
+    "td_tick_release_workspace": (None, []),
     "td_pool2": (ctypes.c_int, [ctypes.c_int, c_i32p, c_i32p, c_i32p, ctypes.c_int, c_i32p, c_i32p, c_i32p, c_i32p,
                                 ctypes.POINTER(ctypes.c_int32)]),
     "td_pool_n": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, ctypes.c_int, ctypes.c_int,

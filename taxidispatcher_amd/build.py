@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", f) for f in ("td_core.hip", "td_assign.hip", "td_lcm.hip", "td_pool.hip", "td_line.hip")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("td_core.hip", "td_assign.hip", "td_lcm.hip", "td_pool.hip", "td_line.hip", "td_tick.hip")]
 HDR = [os.path.join(HERE, "csrc", "td_common.h"), os.path.join(HERE, "csrc", "td_forest.h"), os.path.join(ROOT, "include", "taxidispatcher_amd.h")]
 LIB = os.environ.get("TD_LIB_OUT") or os.path.join(HERE, "libtaxidispatcher_amd.so")
 

@@ -166,6 +166,7 @@ int g_shape = 1;            // TD_SHAPE         probe for constant columns and s
 int g_shape_max_n = 1 << 20; // TD_SHAPE_MAX_N   largest n the probe runs for
 int g_narrow_price = 1;     // TD_NARROW_PRICE  4-byte cells with a row range <= 2^22: 32-bit prices and labels first (redone in 64 bits if a price reaches 2^27)
 long long g_np_plimit = NP_PLIMIT;   // TD_NP_PLIMIT  (tests) lower price limit of the narrow-price mode in k_assign / k_pcommit
+int g_fuse_t = 1;           // TD_FUSE_T        padded models (dummy requests): one fused transpose + compress pass, no 1-byte attempt
 int g_forest = 1;           // TD_FOREST        cooperative incremental shortest-path forest (k_forest) as the finisher of 4-byte rows
 int g_forest_min_n = 2048;  // TD_FOREST_MIN_N  smallest n it is used for
 long long g_forest_w0 = 16; // TD_FOREST_W0     first label window
@@ -205,6 +206,7 @@ void read_tunables()
     if (const char *e = getenv("TD_LDS_GRID")) g_lds_grid = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("TD_NARROW_PRICE")) g_narrow_price = atoi(e) != 0;
     if (const char *e = getenv("TD_NP_PLIMIT")) g_np_plimit = std::max(1ll, std::min((long long)NP_PLIMIT, atoll(e)));
+    if (const char *e = getenv("TD_FUSE_T")) g_fuse_t = atoi(e) != 0;
     if (const char *e = getenv("TD_FOREST")) g_forest = atoi(e) != 0;
     if (const char *e = getenv("TD_FOREST_MIN_N")) g_forest_min_n = std::max(64, atoi(e));
     if (const char *e = getenv("TD_FOREST_W0")) g_forest_w0 = std::max(1ll, atoll(e));
@@ -640,10 +642,12 @@ __global__ __launch_bounds__(256) void k_bid_row(int n, int nrows, int row0, int
     __shared__ int s_p[4];
     if (ctl[CTL_FLAG]) return;
     if (round > 0 && ctl[CTL_PROG + round - 1] == 0) return;
-    const int lrow = blockIdx.x;
-    if (lrow >= nrows || r2c[lrow] != -1) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const size_t pitch = (size_t)nchunks * E;
+    // grid-stride over the rows: a late round has a handful of bidders, and spawning one workgroup per ROW just to
+    // see that it is assigned cost more than the round's work (16 384 exits = 6.5 us; 2 048 looping workgroups = 2.5)
+    for (int lrow = blockIdx.x; lrow < nrows; lrow += gridDim.x) {
+    if (r2c[lrow] != -1) continue;   // uniform
     const int row = row0 + lrow;
     const CT *rp = cc + (size_t)lrow * pitch;
     const uint32_t hsh = ((uint32_t)row + 1u) * 0x9E3779B1u + (uint32_t)round * 0x85EBCA6Bu;
@@ -723,6 +727,8 @@ __global__ __launch_bounds__(256) void k_bid_row(int n, int nrows, int row0, int
                 atomicMax(&bid[j1], ((unsigned long long)newp << ROW_BITS) | (unsigned long long)(row + 1));
             }
         }
+    }
+    __syncthreads();   // the reduction scratch is reused by the next row
     }
 }
 
@@ -911,6 +917,83 @@ __global__ __launch_bounds__(256) void k_transpose(int n, const int32_t *__restr
         const int j = bx + r, i = by + tx;
         if (i < n && j < n) out[(int64_t)j * n + i] = tile[tx][r];
     }
+}
+
+// Fused transpose + compress for padded models (dummy requests = constant trailing columns, Simulator.java:493-520,
+// simulate.py:17-33): ONE pass over the caller's int32 matrix writes the TRANSPOSED problem's 4-byte cells
+// out[j][i] = in[i][j] - base (pitch npad, pad cells = sentinel) — instead of a void 1-byte compress pass, a
+// transpose into a second int32 matrix and a 4-byte compress pass of that.  The transposed rows keep `base` as
+// their row constant (any constant <= the row minimum is a valid row dual); their minimum / maximum (constant
+// rows = dummy requests are deferred, the range decides the price width) are reduced per workgroup in LDS and
+// merged with one atomic per column and workgroup.  A cell below base or a range beyond 32 bits raises CTL_FLAG:
+// the host then takes the general path.
+template <int RT>
+__global__ __launch_bounds__(256) void k_compress_tr(int n, int npad, const int32_t *__restrict__ in, uint32_t *__restrict__ out, int base,
+                                                     int *__restrict__ colmin, int *__restrict__ colmax, int *__restrict__ ctl)
+{
+    __shared__ int32_t tile[64][65];
+    __shared__ int s_mn[64], s_mx[64];
+    const int bx = blockIdx.x * 64, ry0 = blockIdx.y * (64 * RT);
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    if (tid < 64) {
+        s_mn[tid] = INT_MAX;
+        s_mx[tid] = INT_MIN;
+    }
+    bool bad = false;
+    for (int rt = 0; rt < RT; rt++) {
+        const int by = ry0 + rt * 64;
+        if (by >= n) break;
+        __syncthreads();
+        for (int r = ty; r < 64; r += 4) {
+            const int i = by + r, j = bx + tx;
+            tile[r][tx] = (i < n && j < n) ? in[(int64_t)i * n + j] : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int rr = (tid >> 4) + 16 * k, cq = (tid & 15) * 4;
+            const int j = bx + rr;
+            if (j < n && by + cq < npad) {
+                uint32_t o[4];
+                int mn = INT_MAX, mx = INT_MIN;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int v = tile[cq + e][rr];
+                    if (by + cq + e < n) {
+                        mn = min(mn, v);
+                        mx = max(mx, v);
+                        o[e] = (uint32_t)(v - base);
+                        bad = bad || v < base;
+                    } else
+                        o[e] = 0xFFFFFFFFu;
+                }
+                *reinterpret_cast<uint4 *>(out + (size_t)j * npad + by + cq) = make_uint4(o[0], o[1], o[2], o[3]);
+                if (mn <= mx) {
+                    atomicMin(&s_mn[rr], mn);
+                    atomicMax(&s_mx[rr], mx);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 64 && bx + tid < n && s_mn[tid] <= s_mx[tid]) {
+        atomicMin(&colmin[bx + tid], s_mn[tid]);
+        atomicMax(&colmax[bx + tid], s_mx[tid]);
+    }
+    if (bad) atomicOr(&ctl[CTL_FLAG], 1);
+}
+
+__global__ void k_tr_finish(int n, int base, const int *__restrict__ colmin, const int *__restrict__ colmax, int32_t *__restrict__ rowmin,
+                            int *__restrict__ rconst, int *__restrict__ ctl)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int mn = colmin[j], mx = colmax[j];
+    rowmin[j] = base;
+    const int cst = (mn == mx) ? 1 : 0;
+    rconst[j] = cst;
+    if (cst) atomicAdd(&ctl[CTL_NCONST], 1);
+    atomicMax(reinterpret_cast<unsigned long long *>(&ctl[CTL_RANGE]), (unsigned long long)((int64_t)mx - (int64_t)base));
 }
 
 // =====================================================================================
@@ -2402,7 +2485,7 @@ __global__ __launch_bounds__(1024) void k_pcommit(int n, PT *__restrict__ pk, in
 // =====================================================================================
 __global__ __launch_bounds__(256) void k_final(int n, int nrows, int row0, const int32_t *__restrict__ cost,
                                                const int *__restrict__ r2c, const int *__restrict__ owner,
-                                               unsigned long long *__restrict__ out, int *__restrict__ ctl)
+                                               unsigned long long *__restrict__ out, int *__restrict__ ctl, int cost_is_transposed = 0)
 {
     if (ctl[CTL_FLAG]) return;
     long long s = 0;
@@ -2411,8 +2494,8 @@ __global__ __launch_bounds__(256) void k_final(int n, int nrows, int row0, const
         const int j = r2c[i];
         if (j < 0 || j >= n || owner[j] != row0 + i)
             bad = 1;
-        else
-            s += cost[(int64_t)i * n + j];
+        else   // the fused transposed solve never materialises the transposed int32 matrix: its cell (i, j) is the caller's (j, i)
+            s += cost_is_transposed ? cost[(int64_t)j * n + i] : cost[(int64_t)i * n + j];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -2513,6 +2596,7 @@ struct td_shard {
     int nconst = -1;                 // constant rows counted by the last compress pass (-1: not read back)
     const int32_t *probe = nullptr;  // non-null for the one k_init_state launch that carries the shape probe
     bool placed = false;       // ... and the finisher kernel has already placed them (no k_place_const launch)
+    bool fused_t = false;      // cc holds the TRANSPOSED problem built straight from the caller's matrix (k_compress_tr): d_cost is not transposed
     const long long *skip = nullptr;  // device flag of a pending line-metric probe: non-zero makes the compress pass a no-op
     void free_all()
     {
@@ -2622,6 +2706,43 @@ int sv_compress(Solver &sv, int bpc, bool *fits, bool speculate = false)
     return fail(TD_EINVAL, "bytes per cell must be 1, 2 or 4");
 }
 
+// padded model: the transposed problem's 4-byte cells straight from the caller's matrix (k_compress_tr)
+int sv_compress_fused(Solver &sv, bool *fits, int64_t *range)
+{
+    Ctx &c = ctx();
+    const int n = sv.n;
+    const int nchunks = (n + 3) / 4, npad = nchunks * 4;
+    int rc;
+    if ((rc = ensure(sv.cc, std::max<size_t>((size_t)n * nchunks * 16, 256)))) return rc;
+    int *ctl = (int *)sv.misc.p;
+    TD_HIP(hipMemsetAsync(ctl, 0, CTL_ALL * sizeof(int), c.stream));
+    int *colmin = (int *)sv.pred.p, *colmax = (int *)sv.list.p;   // free until the finisher
+    {
+        ProfScope ps(TD_K_COMPRESS);
+        k_fill_i32<<<(n + 255) / 256, 256, 0, c.stream>>>(colmin, n, INT_MAX);
+        k_fill_i32<<<(n + 255) / 256, 256, 0, c.stream>>>(colmax, n, INT_MIN);
+        if (n > 4096)   // tall workgroups: fewer atomics per column; small models need the workgroups instead
+            k_compress_tr<8><<<dim3((n + 63) / 64, (n + 511) / 512), 256, 0, c.stream>>>(n, npad, sv.d_cost, (uint32_t *)sv.cc.p, 0, colmin, colmax, ctl);
+        else
+            k_compress_tr<1><<<dim3((n + 63) / 64, (n + 63) / 64), 256, 0, c.stream>>>(n, npad, sv.d_cost, (uint32_t *)sv.cc.p, 0, colmin, colmax, ctl);
+        k_tr_finish<<<(n + 255) / 256, 256, 0, c.stream>>>(n, 0, colmin, colmax, (int32_t *)sv.rowmin.p, (int *)sv.rconst.p, ctl);
+    }
+    TD_HIP(hipGetLastError());
+    TD_HIP(hipMemcpyAsync(c.pinned, ctl, 8 * sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    TD_HIP(hipStreamSynchronize(c.stream));
+    const int *h = (const int *)c.pinned;
+    *range = (int64_t)(((const unsigned long long *)(h + CTL_RANGE))[0]);
+    *fits = h[CTL_FLAG] == 0 && *range <= (int64_t)Tr<uint32_t>::LIMIT;
+    sv.nconst = h[CTL_NCONST];
+    if (*fits) {
+        sv.nchunks = nchunks;
+        sv.npad = npad;
+        // the range word is a "did not fit" report for the regular passes: clear it and the flag for the solve
+        TD_HIP(hipMemsetAsync(ctl + CTL_RANGE, 0, 2 * sizeof(int), c.stream));
+    }
+    return TD_OK;
+}
+
 template <typename CT>
 int sv_begin_t(Solver &sv)
 {
@@ -2655,7 +2776,7 @@ int sv_bid_t(Solver &sv, int r, unsigned long long *keys)
         k_bid<CT, true><<<grid, 1024, lds_prices, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
                                                               (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict, 1, 0, tied);
     } else if (r >= g_row_rounds) {
-        k_bid_row<CT><<<nrows, 256, 0, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
+        k_bid_row<CT><<<std::min(nrows, c.n_cu * 8), 256, 0, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
                                                    (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict);
     } else {
         k_bid<CT, false><<<(nrows + 3) / 4, 256, 0, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
@@ -2709,6 +2830,11 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
         if (g_forest && n >= g_forest_min_n && n <= 32768 && tab.count == 1) {
             Ctx &c = ctx();
             using PT = typename Tr<CT>::PT;
+            {   // nothing left for a finisher (thresholded models, easy instances): no cooperative launch for it
+                TD_HIP(hipMemcpyAsync(c.pinned, (int *)sv.misc.p + CTL_NFREE, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+                TD_HIP(hipStreamSynchronize(c.stream));
+                if (((int *)c.pinned)[0] == 0) return TD_OK;
+            }
             typedef typename std::conditional<sizeof(PT) == 4, int, long long>::type LT;
             const size_t off_base = (sizeof(FoShared) + 255) / 256 * 256;
             const size_t n4 = (size_t)(n + 3) / 4 * 4;   // the int arrays start 16-byte aligned and are padded (16-byte loads)
@@ -2962,7 +3088,7 @@ int sv_totals_t(Solver &sv, bool want_dual)
     ProfScope ps(TD_K_FINAL);
     if (sv.nrows > 0)
         k_final<<<std::min((sv.nrows + 255) / 256, 256), 256, 0, c.stream>>>(sv.n, sv.nrows, sv.row0, sv.d_cost, (const int *)sv.r2c.p,
-                                                                            (const int *)sv.owner.p, out, (int *)sv.misc.p);
+                                                                            (const int *)sv.owner.p, out, (int *)sv.misc.p, sv.fused_t ? 1 : 0);
     if (want_dual && (sv.nrows > 0 || sv.row0 == 0))
         k_dual<CT><<<std::max(1, std::min((sv.nrows + 3) / 4, c.n_cu * 8)), 256, 0, c.stream>>>(
             sv.n, sv.nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p, (const int32_t *)sv.rowmin.p, out);
@@ -3132,6 +3258,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     if (n >= (1 << ROW_BITS) - 1) return fail(TD_ERANGE, "n=%d exceeds the packed bid key", n);
     Solver &sv = g_default;
     sv.skip = nullptr;
+    sv.fused_t = false;
     int rc;
     if ((rc = sv_prepare(sv, n, 0, n, cost))) return rc;
     int64_t tot = 0, dual = 0;
@@ -3170,6 +3297,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     int64_t known_range = transposed ? range_hint : -1;
     for (int bpc : {1, 2, 5, 4}) {   // 5 = 4-byte cells with 32-bit prices (narrow-price mode, see u32n)
         bool fits = false;
+        if (sv.fused_t && bpc != 5 && bpc != 4) continue;   // the fused pass has written 4-byte cells
         if (known_range > 254 && bpc == 1) continue;    // the probe's sampled column range: u8 cannot hold it
         if (known_range > 65534 && bpc == 2) continue;  // u16 cannot hold it either
         if (bpc == 5 && (!g_narrow_price || g_solver_eps || np_failed || known_range < 0 || known_range > NP_RANGE)) continue;
@@ -3180,13 +3308,40 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         // u8 is tried speculatively (no host round trip in the common case)
         const bool spec = (bpc == 1) && g_speculate;
     compress_pass:
-        if ((rc = sv_compress(sv, bpc, &fits, spec))) return rc;
+        if (sv.fused_t) {   // cc already holds the transposed problem (k_compress_tr); the same bytes serve both price widths
+            fits = true;
+            sv.bpc = bpc;
+        } else if ((rc = sv_compress(sv, bpc, &fits, spec)))
+            return rc;
         if (line_pending) {
             line_pending = false;
             sv.skip = nullptr;
-            int mode = 0, kd = 0, accepted = 0, susp = 0;
-            if ((rc = line_probe_wait(&mode, &kd, &susp))) return rc;
-            early_check = susp != 0;
+            int mode = 0, kd = 0, accepted = 0, susp = 0, shape3[3] = {0, 0, 0};
+            if ((rc = line_probe_wait(&mode, &kd, &susp, shape3))) return rc;
+            if (mode == 0 && susp) {
+                // The probe made the speculative 1-byte pass queued behind it a no-op (its device flag): that attempt
+                // was going to be void — row 0 is too wide for one byte, or the model is padded with dummy requests.
+                const int margin = n / 256 > 32 ? n / 256 : 32;   // the rule of the shape probe (k_init_state), on the probe's estimate
+                if (g_fuse_t && g_shape && !g_solver_eps && shape3[0] >= 16 && shape3[0] - shape3[1] >= margin) {
+                    bool ff = false;
+                    int64_t fr = 0;
+                    if ((rc = sv_compress_fused(sv, &ff, &fr))) return rc;
+                    if (getenv("TD_DEBUG")) fprintf(stderr, "[td] fused transpose + compress: n=%d fits %d range %lld, %d constant rows\n", n, (int)ff, (long long)fr, sv.nconst);
+                    if (ff) {
+                        sv.fused_t = true;
+                        transposed = true;
+                        known_range = fr;
+                        continue;   // on to the 4-byte widths
+                    }
+                    goto compress_pass;   // negative cells or a range beyond 32 bits: the general path, from the 1-byte attempt
+                }
+                if (shape3[2]) {   // row 0 does not fit one byte per cell: skip the 1-byte attempt, the next width measures the range
+                    known_range = std::max<int64_t>(known_range, 255);
+                    continue;
+                }
+                goto compress_pass;   // only a hint that did not lead anywhere: run the skipped pass
+            }
+            early_check = false;
             if (getenv("TD_DEBUG")) fprintf(stderr, "[td] line probe: n=%d verdict %d, %d constant rows, suspicious %d\n", n, mode, kd, susp);
             if (mode) {
                 const int32_t *res = nullptr;

@@ -302,6 +302,7 @@ __global__ void k_count_sum(int n, const int32_t *cost, const int32_t *row_to_co
 // API
 // =====================================================================================
 extern "C" void td_assign_release_workspace(void);
+extern "C" void td_tick_release_workspace(void);
 
 extern "C" {
 
@@ -345,6 +346,7 @@ void td_shutdown(void)
     (void)hipSetDevice(c.device);
     (void)hipDeviceSynchronize();
     td_assign_release_workspace();
+    td_tick_release_workspace();
     Buf *bufs[] = {&c.stage_a, &c.stage_b, &c.stage_c, &c.stage_d, &c.stage_out, &c.cc,
                    &c.misc,    &c.lcm_a,   &c.lcm_b,   &c.lcm_c,   &c.lcm_d};
     for (Buf *b : bufs) {

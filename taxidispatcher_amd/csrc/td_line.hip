@@ -36,7 +36,7 @@ namespace {
 
 // LC_PLAUS: 0 refused; 1 balanced line metric plausible; 2 constant trailing COLUMNS (retry on the transpose);
 //           3 plausible with LC_K constant rows (the unbalanced model: fewer cabs than requests)
-enum { LC_P = 0, LC_Q, LC_I1, LC_I2, LC_PLAUS, LC_REV, LC_FAIL, LC_FITS32, LC_TOTAL, LC_K, LC_FILL, LC_WORDS };
+enum { LC_P = 0, LC_Q, LC_I1, LC_I2, LC_PLAUS, LC_REV, LC_FAIL, LC_FITS32, LC_TOTAL, LC_K, LC_FILL, LC_SKIP, LC_WORDS };
 constexpr int LINE_KMAX = 32;   // most constant rows the unbalanced plan is made for
 
 struct LineWs {
@@ -120,7 +120,33 @@ __global__ __launch_bounds__(1024) void k_line_probe(int n, const int32_t *__res
     const bool cols_dummy = !__syncthreads_or(colvar);
     // a hint for td_assign's speculative 1-byte attempt: it will fail (row 0 is too wide) or is likely to ask for the
     // transpose (constant last column): worth one early look at its flag instead of ~30 launches that exit at once
-    const int suspicious = __syncthreads_or(far) || cols_dummy;
+    const int far_any = __syncthreads_or(far);
+    const int suspicious = far_any || cols_dummy;
+    // shape estimate for td_assign (only when the last column looks like a dummy request): how many of 1024 sampled
+    // columns / rows are constant over 16 sampled cells — the same test as the shape probe of k_init_state, but
+    // BEFORE any compress pass, so that a padded model goes straight to the transposed formulation
+    int est_cc = 0, est_cr = 0;
+    if (cols_dummy) {
+        // 256 sampled columns / rows, 8 sampled cells each: the estimate only chooses between two exact formulations
+        const int step4 = n > 256 ? n / 256 : 1;
+        const int ns4 = (n + step4 - 1) / step4;
+        int ccol = 0, crow = 0;
+        if (t < ns4) {
+            const int j = t * step4, i = t * step4;
+            const int32_t v0 = c[j], w0r = c[(size_t)i * n];
+            int same_c = 1, same_r = 1;
+#pragma unroll
+            for (int k = 1; k < 8; k++) {
+                const size_t kk = (size_t)(((long long)k * n) >> 3);
+                same_c &= c[kk * n + j] == v0;
+                same_r &= c[(size_t)i * n + kk] == w0r;
+            }
+            ccol = same_c;
+            crow = same_r;
+        }
+        est_cc = __syncthreads_count(ccol) * step4;
+        est_cr = __syncthreads_count(crow) * step4;
+    }
     if (cols_dummy) {
         // before the host pays for a transpose: columns 0 and 1 over the first 1024 ROWS must pass step 0 too
         // (a thresholded simulator model with dummy requests is refused here)
@@ -259,6 +285,10 @@ __global__ __launch_bounds__(1024) void k_line_probe(int n, const int32_t *__res
         ctl[LC_TOTAL] = 0;
         ctl[LC_K] = kdummy;
         ctl[LC_FILL] = B0;
+        ctl[LC_SKIP] = (mode != 0 || suspicious) ? 1 : 0;   // the speculative 1-byte compress pass queued behind this probe is void either way
+        host_verdict[3] = est_cc;
+        host_verdict[4] = est_cr;
+        host_verdict[5] = far_any;
         host_verdict[0] = mode;
         host_verdict[1] = kdummy;
         host_verdict[2] = suspicious;
@@ -692,11 +722,11 @@ int line_probe_launch(int n, const int32_t *d_cost, const long long **skip_dev)
         TD_HIP(hipGetLastError());
     }
     TD_HIP(hipEventRecord(g_probe_done, c.stream));
-    *skip_dev = ctl + LC_PLAUS;
+    *skip_dev = ctl + LC_SKIP;
     return TD_OK;
 }
 
-int line_probe_wait(int *mode, int *k, int *suspicious)
+int line_probe_wait(int *mode, int *k, int *suspicious, int *shape3)
 {
     Ctx &c = ctx();
     TD_HIP(hipEventSynchronize(g_probe_done));
@@ -704,6 +734,11 @@ int line_probe_wait(int *mode, int *k, int *suspicious)
     *mode = (int)h[0];
     *k = (int)h[1];
     if (suspicious) *suspicious = (int)h[2];
+    if (shape3) {   // estimated constant columns, estimated constant rows, row 0 too wide for one byte per cell
+        shape3[0] = (int)h[3];
+        shape3[1] = (int)h[4];
+        shape3[2] = (int)h[5];
+    }
     return TD_OK;
 }
 

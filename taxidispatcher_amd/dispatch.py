@@ -223,6 +223,36 @@ def LCM_simulator(cost, max_non_lcm=600, big_cost=BIG_COST, as_arrays=False):
     return list(zip(map(int, rows), map(int, cols))), lm
 
 
+def tick(cab_to, dem_from, distances=None, big_cost=BIG_COST, drop_time=10, max_non_lcm=600):
+    """One dispatcher tick in one C-ABI call (td_tick): calculate_cost -> LCM down to max_non_lcm rows ->
+    removal of the matched cabs / requests on the device -> calculate_cost -> optimal assignment
+    (Simulator.java:163-208,493-549,613-674; greedy_opt.py:32-37).  cab_to / dem_from: the stands the free cabs
+    stand at / the requests start from.  Returns a dict: lcm_rows, lcm_cols (int32 arrays, the reference's pick
+    order), lcm_min_val, kept_cabs, kept_dems (positions handed to the solver, in order), n_rest, row_to_col
+    (int32[n_rest], indices into kept_cabs -> kept_dems; >= len(kept_dems) or a cab index >= len(kept_cabs): dummy),
+    total (the remainder's optimum, dummy cells count big_cost)."""
+    lib = _ffi.lib()
+    cab = cab_to if hasattr(cab_to, "data_ptr") else _ffi.as_i32(cab_to)
+    dem = dem_from if hasattr(dem_from, "data_ptr") else _ffi.as_i32(dem_from)
+    n_s, n_d = int(cab.shape[0]), int(dem.shape[0])
+    n = max(n_s, n_d)
+    dptr, S, keep = _dist_arg(distances)
+    rows = np.empty(max(n, 1), np.int32)
+    cols = np.empty(max(n, 1), np.int32)
+    kc = np.empty(max(n_s, 1), np.int32)
+    kd = np.empty(max(n_d, 1), np.int32)
+    r2c = np.empty(max(n, 1), np.int32)
+    k, lm, n2, tot = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int64(0)
+    _ffi.check(lib.td_tick(_ffi.addr(cab) if n_s else None, n_s, _ffi.addr(dem) if n_d else None, n_d, dptr, S, int(big_cost),
+                           -1 if drop_time is None else int(drop_time), -1 if max_non_lcm is None else int(max_non_lcm),
+                           _ffi.addr(rows), _ffi.addr(cols), ctypes.byref(k), ctypes.byref(lm), _ffi.addr(kc), _ffi.addr(kd),
+                           ctypes.byref(n2), _ffi.addr(r2c), ctypes.byref(tot)))
+    del keep
+    kk = k.value
+    return {"lcm_rows": rows[:kk], "lcm_cols": cols[:kk], "lcm_min_val": lm.value, "kept_cabs": kc[:n_s - kk],
+            "kept_dems": kd[:n_d - kk], "n_rest": n2.value, "row_to_col": r2c[:n2.value], "total": tot.value}
+
+
 def find_pool(frm, to, distances=None):
     """Simulator.java:681-758 findPool on the GPU: requests given by their from/to stands ->
     list of (custA, custB, plan, cost) in the order the reference keeps them."""

@@ -94,6 +94,49 @@ def test_config5_tick_pipeline_gpu(td):
 
 
 @pytest.mark.gpu
+def test_config5_tick_in_one_call_gpu(td):
+    """The same tick behind ONE C-ABI call (td_tick: the shrink runs on the device, Simulator.java:163-208,613-674)
+    against the oracle's pipeline: pair list, LCM_min_val, the kept cabs / requests, the remainder's optimum; plus
+    the shapes a tick loop meets: fewer cabs than requests, no LCM needed, a general distance table, an empty model."""
+    from oracle import oracle
+    from taxidispatcher_amd.simulator import BIG_COST, DROP_TIME, MAX_NON_LCM
+
+    def reference(cab_to, dem_from, dist, stop):
+        n_o, cost_o = oracle.cost_build(cab_to, dem_from, dist, BIG_COST, DROP_TIME)
+        if 0 <= stop < n_o:
+            _, rows, cols, lm = oracle.lcm(cost_o, mask=BIG_COST, stop_value_on=1, stop_value=BIG_COST, stop_size=stop,
+                                           sum_below=BIG_COST, java_scan=1)
+        else:
+            rows, cols, lm = np.zeros(0, np.int64), np.zeros(0, np.int64), BIG_COST
+        keep_c = np.setdiff1d(np.arange(len(cab_to)), rows)
+        keep_d = np.setdiff1d(np.arange(len(dem_from)), cols)
+        n2, cost2 = oracle.cost_build(np.asarray(cab_to)[keep_c], np.asarray(dem_from)[keep_d], dist, BIG_COST, DROP_TIME)
+        tot = oracle.assign(cost2)[0] if n2 else 0
+        return rows, cols, lm, keep_c, keep_d, n2, cost2, tot
+
+    rng = np.random.default_rng(49)
+    S = 50
+    table = rng.integers(0, 25, (S, S)).astype(np.int32)   # a general (asymmetric) table, PDF Table 2
+    cases = [(rng.integers(0, 50, 1300), rng.integers(0, 50, 900), None, MAX_NON_LCM),
+             (rng.integers(0, 50, 700), rng.integers(0, 50, 1100), None, MAX_NON_LCM),
+             (rng.integers(0, 50, 500), rng.integers(0, 50, 218), None, MAX_NON_LCM),     # n <= MAX_NON_LCM: no LCM
+             (rng.integers(0, S, 900), rng.integers(0, S, 900), table, 250)]
+    for cab_to, dem_from, dist, stop in cases:
+        rows, cols, lm, keep_c, keep_d, n2, cost2, tot = reference(cab_to, dem_from, dist, stop)
+        t = td.tick(cab_to, dem_from, dist, big_cost=BIG_COST, drop_time=DROP_TIME, max_non_lcm=stop)
+        assert t["lcm_rows"].tolist() == rows.tolist() and t["lcm_cols"].tolist() == cols.tolist()
+        if len(rows):
+            assert t["lcm_min_val"] == lm
+        assert t["kept_cabs"].tolist() == keep_c.tolist() and t["kept_dems"].tolist() == keep_d.tolist()
+        assert t["n_rest"] == n2 and t["total"] == tot
+        r2c = t["row_to_col"]
+        assert sorted(r2c.tolist()) == list(range(n2))
+        assert int(cost2[np.arange(n2), r2c].astype(np.int64).sum()) == tot
+    t = td.tick(np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert t["n_rest"] == 0 and len(t["lcm_rows"]) == 0 and t["total"] == 0
+
+
+@pytest.mark.gpu
 def test_pool_of_two_gpu_matches_host_restatement(td):
     """f-3: td_pool2 (symmetric lowest-cost method on the pair-cost matrix) against the numpy
     restatement of Simulator.java:681-758 used by the oracle-backed replay."""
