@@ -106,6 +106,35 @@ struct IsNP<u32n> {
     static constexpr bool value = true;
 };
 
+// 1-byte cells with ONE escape value per matrix (bpc code 6): padded / thresholded models hold a small range of
+// real costs plus the fill value big_cost (Simulator.java:493-520, simulate.py:17-33: {0..9} and 250000).  Codes
+// 0..253 are value - base, 254 is the fill value (g_esc8 = fill - base on the device), 255 pads the row.  Prices
+// and labels are 32-bit as for plain 1-byte rows; with big_cost in play they are guarded like the narrow-price
+// mode (NP_PLIMIT, CTL_FLAG bit 3 -> the host redoes the solve with 4-byte cells).
+constexpr uint32_t U8E_ESC = 254u;
+__device__ uint32_t g_esc8;   // the escape code's value of the matrix being solved (one solver per process)
+struct u8e {
+    uint8_t v;
+    __device__ __forceinline__ operator uint32_t() const { return v == U8E_ESC ? g_esc8 : (uint32_t)v; }   // single-cell reads
+};
+template <>
+struct Tr<u8e> {
+    using PT = int32_t;
+    static constexpr int E = 16;
+    static constexpr uint32_t SENT = 0xFFu;
+    static constexpr int64_t LIMIT = 253;
+    static constexpr int32_t BIG = 1 << 28;
+    static constexpr int32_t KMAX = INT32_MAX;
+};
+template <>
+struct IsNP<u8e> {
+    static constexpr bool value = true;
+};
+template <typename CT>
+struct IsLean8 {   // plain 1-byte rows: the lean finisher k_sap8 and the speculative first attempt
+    static constexpr bool value = std::is_same<CT, uint8_t>::value;
+};
+
 // control block (int32 words) in device memory
 enum {
     CTL_FLAG = 0,      // compress: row range did not fit
@@ -166,7 +195,8 @@ int g_shape = 1;            // TD_SHAPE         probe for constant columns and s
 int g_shape_max_n = 1 << 20; // TD_SHAPE_MAX_N   largest n the probe runs for
 int g_narrow_price = 1;     // TD_NARROW_PRICE  4-byte cells with a row range <= 2^22: 32-bit prices and labels first (redone in 64 bits if a price reaches 2^27)
 long long g_np_plimit = NP_PLIMIT;   // TD_NP_PLIMIT  (tests) lower price limit of the narrow-price mode in k_assign / k_pcommit
-int g_fuse_t = 1;           // TD_FUSE_T        padded models (dummy requests): one fused transpose + compress pass, no 1-byte attempt
+int g_fuse_t = 2;           // TD_FUSE_T        padded models (dummy requests): one fused transpose + compress pass, no void 1-byte attempt (2: as 1-byte cells + escape when they fit, 1: 4-byte cells, 0: off)
+int g_fused_rounds = 8;      // TD_FUSED_ROUNDS  bidding rounds launched for a padded model taken by the fused pass
 int g_forest = 1;           // TD_FOREST        cooperative incremental shortest-path forest (k_forest) as the finisher of 4-byte rows
 int g_forest_min_n = 2048;  // TD_FOREST_MIN_N  smallest n it is used for
 long long g_forest_w0 = 16; // TD_FOREST_W0     first label window
@@ -206,7 +236,8 @@ void read_tunables()
     if (const char *e = getenv("TD_LDS_GRID")) g_lds_grid = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("TD_NARROW_PRICE")) g_narrow_price = atoi(e) != 0;
     if (const char *e = getenv("TD_NP_PLIMIT")) g_np_plimit = std::max(1ll, std::min((long long)NP_PLIMIT, atoll(e)));
-    if (const char *e = getenv("TD_FUSE_T")) g_fuse_t = atoi(e) != 0;
+    if (const char *e = getenv("TD_FUSE_T")) g_fuse_t = std::max(0, std::min(2, atoi(e)));
+    if (const char *e = getenv("TD_FUSED_ROUNDS")) g_fused_rounds = std::max(1, std::min(48, atoi(e)));
     if (const char *e = getenv("TD_FOREST")) g_forest = atoi(e) != 0;
     if (const char *e = getenv("TD_FOREST_MIN_N")) g_forest_min_n = std::max(64, atoi(e));
     if (const char *e = getenv("TD_FOREST_W0")) g_forest_w0 = std::max(1ll, atoll(e));
@@ -238,6 +269,20 @@ __device__ __forceinline__ void unpack<uint8_t>(const uint4 &v, uint32_t *o)
         o[4 * k + 1] = (w[k] >> 8) & 0xFFu;
         o[4 * k + 2] = (w[k] >> 16) & 0xFFu;
         o[4 * k + 3] = w[k] >> 24;
+    }
+}
+template <>
+__device__ __forceinline__ void unpack<u8e>(const uint4 &v, uint32_t *o)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t esc = g_esc8;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t x = (w[k] >> (8 * b)) & 0xFFu;
+            o[4 * k + b] = (x == U8E_ESC) ? esc : x;
+        }
     }
 }
 template <>
@@ -983,10 +1028,110 @@ __global__ __launch_bounds__(256) void k_compress_tr(int n, int npad, const int3
     if (bad) atomicOr(&ctl[CTL_FLAG], 1);
 }
 
+// The same pass for 1-byte cells with an escape (u8e): every cell is `esc_raw` (the fill value, code 254) or lies in
+// base .. base + 253, else CTL_FLAG is raised and the host redoes the pass with 4-byte cells.  A workgroup takes 64 of
+// the caller's columns x 1024 rows: the codes are staged transposed in LDS (row pitch 1028 bytes = 257 dwords: the 64
+// lanes of a wave hit 64 different banks), then every transposed row leaves as ONE contiguous KiB.
+constexpr int TR8_ROWS = 1024, TR8_LP = TR8_ROWS + 4;
+__global__ __launch_bounds__(256) void k_compress_tr8(int n, int npad, const int32_t *__restrict__ in, uint8_t *__restrict__ out, int base,
+                                                      int esc_raw, int *__restrict__ colmin, int *__restrict__ colmax, int *__restrict__ ctl)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char tb[];   // [64][TR8_LP]
+    __shared__ int s_mn[64], s_mx[64];
+    const int bx = blockIdx.x * 64, ry0 = blockIdx.y * TR8_ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 64) {
+        s_mn[tid] = INT_MAX;
+        s_mx[tid] = INT_MIN;
+    }
+    __syncthreads();
+    // Load phase: lane (cg = lane % 16, rs = lane / 16) of wave w reads 16 bytes = columns 4cg .. 4cg+3 of row 16p + 4w + rs
+    // (a wave reads 4 full 256-byte row pieces per instruction, 8 instructions in flight).  The four lanes cg, cg+16,
+    // cg+32, cg+48 hold a 4 x 4 block (4 rows x 4 columns): each packs its row's codes into one dword, fetches the
+    // other three by shuffles and writes ONE dword = 4 consecutive rows of column 4cg + rs — a conflict-free
+    // ds_write_b32 (dword address (4cg + rs) * 257 + row / 4: 64 different banks over the wave).
+    const int cg = lane & 15, rs = lane >> 4;
+    int mn[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX}, mx[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+    bool bad = false;
+    const int jc0 = bx + 4 * cg;
+    const bool vec = (n % 4 == 0);
+    constexpr int U = 8;
+    for (int p0 = 0; p0 < TR8_ROWS / 16; p0 += U) {
+        int4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int r = 16 * (p0 + u) + 4 * wv + rs, i = ry0 + r;
+            if (i < n && vec && jc0 + 3 < n)
+                v[u] = *reinterpret_cast<const int4 *>(in + (int64_t)i * n + jc0);
+            else {
+                int t4[4];
+#pragma unroll
+                for (int x = 0; x < 4; x++) t4[x] = (i < n && jc0 + x < n) ? in[(int64_t)i * n + jc0 + x] : esc_raw;
+                v[u] = make_int4(t4[0], t4[1], t4[2], t4[3]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int r = 16 * (p0 + u) + 4 * wv + rs, i = ry0 + r;
+            const int vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            uint32_t packed = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                uint32_t code = 0xFFu;
+                if (i < n && jc0 + x < n) {
+                    mn[x] = min(mn[x], vv[x]);
+                    mx[x] = max(mx[x], vv[x]);
+                    const int d = vv[x] - base;
+                    if (vv[x] == esc_raw)
+                        code = U8E_ESC;
+                    else {
+                        code = (uint32_t)d & 0xFFu;
+                        bad = bad || d < 0 || d > 253;
+                    }
+                }
+                packed |= code << (8 * x);
+            }
+            // 4 x 4 transpose over the lanes cg + 16 * q: my dword = byte `rs` of the packed rows q = 0 .. 3
+            uint32_t mine = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t pq = (uint32_t)__shfl((int)packed, cg + 16 * q);
+                mine |= ((pq >> (8 * rs)) & 0xFFu) << (8 * q);
+            }
+            const int rbase = 16 * (p0 + u) + 4 * wv;   // the four rows of this block
+            *reinterpret_cast<uint32_t *>(tb + (size_t)(4 * cg + rs) * TR8_LP + rbase) = mine;
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+        if (mn[x] <= mx[x]) {
+            atomicMin(&s_mn[4 * cg + x], mn[x]);
+            atomicMax(&s_mx[4 * cg + x], mx[x]);
+        }
+    __syncthreads();
+    // wave wv writes the transposed rows wv * 16 .. + 15: lane l holds the dwords l, l + 64, l + 128, l + 192 of the row
+    for (int k = 0; k < 16; k++) {
+        const int rr = wv * 16 + k, jj = bx + rr;
+        if (jj >= n) break;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(tb + (size_t)rr * TR8_LP);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int dw = lane + 64 * q, b = ry0 + 4 * dw;
+            if (b < npad) *reinterpret_cast<uint32_t *>(out + (size_t)jj * npad + b) = src[dw];
+        }
+    }
+    if (tid < 64 && bx + tid < n && s_mn[tid] <= s_mx[tid]) {
+        atomicMin(&colmin[bx + tid], s_mn[tid]);
+        atomicMax(&colmax[bx + tid], s_mx[tid]);
+    }
+    if (bad) atomicOr(&ctl[CTL_FLAG], 1);
+}
+
 __global__ void k_tr_finish(int n, int base, const int *__restrict__ colmin, const int *__restrict__ colmax, int32_t *__restrict__ rowmin,
-                            int *__restrict__ rconst, int *__restrict__ ctl)
+                            int *__restrict__ rconst, int *__restrict__ ctl, int esc_raw = 0, int with_esc = 0)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0 && with_esc) g_esc8 = (uint32_t)(esc_raw - base);
     if (j >= n) return;
     const int mn = colmin[j], mx = colmax[j];
     rowmin[j] = base;
@@ -1127,6 +1272,7 @@ __global__ __launch_bounds__(TB) void k_sap(int n, int nchunks, const ShardTab t
 
     if (ctl[CTL_FLAG]) return;
     if (SPEC && (ctl[CTL_PSTOP] || (int)blockIdx.x >= ctl[CTL_NFREE])) return;
+    if (!SPEC && ctl[CTL_NFREE] <= 0) return;   // nothing was left free: no price unpack / re-pack round trip over all columns
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
     const int npad = nchunks * E;
     const size_t pitch = (size_t)npad;
@@ -2597,6 +2743,7 @@ struct td_shard {
     const int32_t *probe = nullptr;  // non-null for the one k_init_state launch that carries the shape probe
     bool placed = false;       // ... and the finisher kernel has already placed them (no k_place_const launch)
     bool fused_t = false;      // cc holds the TRANSPOSED problem built straight from the caller's matrix (k_compress_tr): d_cost is not transposed
+    bool fused8 = false;       // ... as 1-byte cells with the escape code (u8e, bpc code 6)
     const long long *skip = nullptr;  // device flag of a pending line-metric probe: non-zero makes the compress pass a no-op
     void free_all()
     {
@@ -2707,11 +2854,11 @@ int sv_compress(Solver &sv, int bpc, bool *fits, bool speculate = false)
 }
 
 // padded model: the transposed problem's 4-byte cells straight from the caller's matrix (k_compress_tr)
-int sv_compress_fused(Solver &sv, bool *fits, int64_t *range)
+int sv_compress_fused(Solver &sv, bool *fits, int64_t *range, bool cells8 = false, int esc_raw = 0)
 {
     Ctx &c = ctx();
     const int n = sv.n;
-    const int nchunks = (n + 3) / 4, npad = nchunks * 4;
+    const int nchunks = cells8 ? (n + 15) / 16 : (n + 3) / 4, npad = cells8 ? nchunks * 16 : nchunks * 4;
     int rc;
     if ((rc = ensure(sv.cc, std::max<size_t>((size_t)n * nchunks * 16, 256)))) return rc;
     int *ctl = (int *)sv.misc.p;
@@ -2721,18 +2868,24 @@ int sv_compress_fused(Solver &sv, bool *fits, int64_t *range)
         ProfScope ps(TD_K_COMPRESS);
         k_fill_i32<<<(n + 255) / 256, 256, 0, c.stream>>>(colmin, n, INT_MAX);
         k_fill_i32<<<(n + 255) / 256, 256, 0, c.stream>>>(colmax, n, INT_MIN);
-        if (n > 4096)   // tall workgroups: fewer atomics per column; small models need the workgroups instead
+        if (cells8) {
+            const size_t shm = (size_t)64 * TR8_LP;
+            (void)hipFuncSetAttribute((const void *)k_compress_tr8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            k_compress_tr8<<<dim3((n + 63) / 64, (n + TR8_ROWS - 1) / TR8_ROWS), 256, shm, c.stream>>>(n, npad, sv.d_cost, (uint8_t *)sv.cc.p, 0, esc_raw,
+                                                                                                      colmin, colmax, ctl);
+        } else if (n > 4096)   // tall workgroups: fewer atomics per column; small models need the workgroups instead
             k_compress_tr<8><<<dim3((n + 63) / 64, (n + 511) / 512), 256, 0, c.stream>>>(n, npad, sv.d_cost, (uint32_t *)sv.cc.p, 0, colmin, colmax, ctl);
         else
             k_compress_tr<1><<<dim3((n + 63) / 64, (n + 63) / 64), 256, 0, c.stream>>>(n, npad, sv.d_cost, (uint32_t *)sv.cc.p, 0, colmin, colmax, ctl);
-        k_tr_finish<<<(n + 255) / 256, 256, 0, c.stream>>>(n, 0, colmin, colmax, (int32_t *)sv.rowmin.p, (int *)sv.rconst.p, ctl);
+        k_tr_finish<<<(n + 255) / 256, 256, 0, c.stream>>>(n, 0, colmin, colmax, (int32_t *)sv.rowmin.p, (int *)sv.rconst.p, ctl, esc_raw,
+                                                           cells8 ? 1 : 0);
     }
     TD_HIP(hipGetLastError());
     TD_HIP(hipMemcpyAsync(c.pinned, ctl, 8 * sizeof(int), hipMemcpyDeviceToHost, c.stream));
     TD_HIP(hipStreamSynchronize(c.stream));
     const int *h = (const int *)c.pinned;
     *range = (int64_t)(((const unsigned long long *)(h + CTL_RANGE))[0]);
-    *fits = h[CTL_FLAG] == 0 && *range <= (int64_t)Tr<uint32_t>::LIMIT;
+    *fits = h[CTL_FLAG] == 0 && *range <= (int64_t)Tr<uint32_t>::LIMIT && *range >= 0;
     sv.nconst = h[CTL_NCONST];
     if (*fits) {
         sv.nchunks = nchunks;
@@ -2891,7 +3044,7 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
     // ---- speculative parallel searches first (a few batches), the serial workgroup mops up
     // (u8 instances go straight to the lean tie-batching serial workgroup, which is faster there)
     int nfree_left = -1;   // free rows the speculative batches left (-1: not read back)
-    if (g_psap_batches > 0 && CH <= 4 && CH * E <= 16 && lds && n >= 64 && sizeof(CT) > 1) {
+    if (g_psap_batches > 0 && CH <= 4 && CH * E <= 16 && lds && n >= 64 && !IsLean8<CT>::value) {
         Ctx &c = ctx();
         using PT = typename Tr<CT>::PT;
         int rc = ensure(sv.psrec, sizeof(PsRec<PT>) * (size_t)PS_G);
@@ -2961,7 +3114,7 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
 #endif
         constexpr int TXsel = (sizeof(CT) == 4) ? TD_SX_TX : 256;
         const int KX = (nchunks + TXsel - 1) / TXsel;
-        const bool lean8 = sizeof(CT) == 1 && CH == 1 && g_sap8;
+        const bool lean8 = IsLean8<CT>::value && CH == 1 && g_sap8;
         bool launched_x = false;
         // from 8 x 256 chunks on always; from 4 x 256 on when many rows are left (|a-b| n = 6000: 190 -> 109 ms with 62 rows;
         // uniform 0..10^6 n = 4096 with 10 rows: 9.8 -> 12.1 ms, so not for a handful)
@@ -2999,7 +3152,7 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
             return TD_OK;
         }
     }
-    if constexpr (sizeof(CT) == 1) {
+    if constexpr (IsLean8<CT>::value) {
         if (CH == 1 && g_sap8) {
             Ctx &c = ctx();
             if (lds && g_psap8_batches > 0 && n >= 64) {
@@ -3193,6 +3346,7 @@ int sv_warm_t(Solver &sv, int64_t range, int64_t *rounds_out)
             case 2: rc = CALL<uint16_t>(__VA_ARGS__); break;        \
             case 4: rc = CALL<uint32_t>(__VA_ARGS__); break;        \
             case 5: rc = CALL<u32n>(__VA_ARGS__); break;            \
+            case 6: rc = CALL<u8e>(__VA_ARGS__); break;             \
             default: rc = fail(TD_EINVAL, "shard is not compressed yet"); \
         }                                                           \
     } while (0)
@@ -3232,7 +3386,7 @@ int sv_readback(Solver &sv, int64_t *total, int64_t *dual, int max_rounds, int *
     c.stats[1] = 0;
     c.stats[2] = hctl[CTL_NFREE];
     c.stats[3] = hctl[CTL_STEPS];
-    c.stats[4] = sv.bpc == 5 ? 4 : sv.bpc;   // bytes per stored cell (mode 5 = 4-byte cells with 32-bit prices)
+    c.stats[4] = sv.bpc == 5 ? 4 : (sv.bpc == 6 ? 1 : sv.bpc);   // bytes per stored cell (mode 5 = 4-byte cells with 32-bit prices, 6 = 1-byte cells + escape)
     c.stats[5] = hctl[CTL_PACC];
     c.stats[10] = hctl[CTL_FOREST];
     return TD_OK;
@@ -3259,6 +3413,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     Solver &sv = g_default;
     sv.skip = nullptr;
     sv.fused_t = false;
+    sv.fused8 = false;
     int rc;
     if ((rc = sv_prepare(sv, n, 0, n, cost))) return rc;
     int64_t tot = 0, dual = 0;
@@ -3288,16 +3443,17 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         line_pending = true;
     }
     c.stats[8] = 0;
-    const int max_rounds = g_max_rounds;
+    int max_rounds = g_max_rounds;
     bool solved = false, transposed = false, np_failed = false;
     int64_t range_hint = -1;
     sv.defer_const = g_defer_const && !g_solver_eps;
     for (int orient = 0; orient < 2 && !solved; orient++) {
     bool want_transpose = false;
     int64_t known_range = transposed ? range_hint : -1;
-    for (int bpc : {1, 2, 5, 4}) {   // 5 = 4-byte cells with 32-bit prices (narrow-price mode, see u32n)
+    for (int bpc : {1, 2, 6, 5, 4}) {   // 5 = 4-byte cells with 32-bit prices (narrow-price mode, see u32n); 6 = 1-byte cells + escape (u8e, fused pass only)
         bool fits = false;
-        if (sv.fused_t && bpc != 5 && bpc != 4) continue;   // the fused pass has written 4-byte cells
+        if (bpc == 6 && !sv.fused8) continue;
+        if (sv.fused_t && (sv.fused8 ? bpc != 6 : (bpc != 5 && bpc != 4))) continue;   // the widths the fused pass has written
         if (known_range > 254 && bpc == 1) continue;    // the probe's sampled column range: u8 cannot hold it
         if (known_range > 65534 && bpc == 2) continue;  // u16 cannot hold it either
         if (bpc == 5 && (!g_narrow_price || g_solver_eps || np_failed || known_range < 0 || known_range > NP_RANGE)) continue;
@@ -3316,7 +3472,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         if (line_pending) {
             line_pending = false;
             sv.skip = nullptr;
-            int mode = 0, kd = 0, accepted = 0, susp = 0, shape3[3] = {0, 0, 0};
+            int mode = 0, kd = 0, accepted = 0, susp = 0, shape3[4] = {0, 0, 0, 0};
             if ((rc = line_probe_wait(&mode, &kd, &susp, shape3))) return rc;
             if (mode == 0 && susp) {
                 // The probe made the speculative 1-byte pass queued behind it a no-op (its device flag): that attempt
@@ -3325,12 +3481,20 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
                 if (g_fuse_t && g_shape && !g_solver_eps && shape3[0] >= 16 && shape3[0] - shape3[1] >= margin) {
                     bool ff = false;
                     int64_t fr = 0;
-                    if ((rc = sv_compress_fused(sv, &ff, &fr))) return rc;
+                    // 1-byte cells + escape first ({small range} u {fill}: every reference model of this kind), else 4-byte cells
+                    if (g_fuse_t >= 2 && n <= 65536) {
+                        if ((rc = sv_compress_fused(sv, &ff, &fr, true, shape3[3]))) return rc;
+                        sv.fused8 = ff;
+                    }
+                    if (!ff && (rc = sv_compress_fused(sv, &ff, &fr))) return rc;
                     if (getenv("TD_DEBUG")) fprintf(stderr, "[td] fused transpose + compress: n=%d fits %d range %lld, %d constant rows\n", n, (int)ff, (long long)fr, sv.nconst);
                     if (ff) {
                         sv.fused_t = true;
                         transposed = true;
                         known_range = fr;
+                        // thresholded models are a few huge tie classes: the rounds stop making progress after 5 - 6
+                        // (profiles/r3), every further launch is ~10 us of early exits; what is left goes to the finisher
+                        max_rounds = std::min(max_rounds, g_fused_rounds);
                         continue;   // on to the 4-byte widths
                     }
                     goto compress_pass;   // negative cells or a range beyond 32 bits: the general path, from the 1-byte attempt
@@ -3493,10 +3657,19 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         if (r2c_in_pinned)
             TD_HIP(hipMemcpyAsync((char *)c.pinned + R2C_PIN_OFF, transposed ? sv.owner.p : sv.r2c.p, sizeof(int32_t) * (size_t)n,
                                   hipMemcpyDeviceToHost, c.stream));
-        if ((rc = sv_readback(sv, &tot, &dual, max_rounds, (spec || bpc == 5) ? &flag : nullptr))) return rc;
+        if ((rc = sv_readback(sv, &tot, &dual, max_rounds, (spec || bpc == 5 || bpc == 6) ? &flag : nullptr))) return rc;
         c.stats[1] = warm_rounds;
         if (bpc == 5 && flag) {   // a price reached the 32-bit limit: the attempt is void, redo with 64-bit prices
             np_failed = true;
+            continue;
+        }
+        if (bpc == 6 && flag) {   // the same guard for the 1-byte cells with the escape: redo the fused pass as 4-byte cells
+            bool ff = false;
+            int64_t fr = 0;
+            sv.fused8 = false;
+            if ((rc = sv_compress_fused(sv, &ff, &fr))) return rc;
+            if (!ff) return fail(TD_EINTERNAL, "fused transpose pass: 4-byte cells refused after the 1-byte ones fitted");
+            known_range = fr;
             continue;
         }
         if (spec && (flag & 4)) {  // many constant columns: solve the transposed problem instead

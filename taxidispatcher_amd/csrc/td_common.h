@@ -63,7 +63,7 @@ int to_device(const void *src, size_t bytes, Buf &stage, const void **out);
 //   line_finish        keys, sort, prices, certificate pass; *accepted = 1: *r2c_dev / *total are proven optimal
 int line_probe_launch(int n, const int32_t *d_cost, const long long **skip_dev);
 int line_probe_wait(int *mode, int *k, int *suspicious = nullptr /* the 1-byte attempt is void: the probe made the queued pass a no-op */,
-                    int *shape3 = nullptr /* estimated constant columns / rows, row 0 too wide for one byte */);
+                    int *shape3 = nullptr /* int[4]: estimated constant columns / rows, row 0 too wide for one byte, value of the last column */);
 int line_finish(int n, int k, const int32_t *d_cost, const int32_t **r2c_dev, int64_t *total, int *accepted);
 void line_release_workspace();
 void prof_begin(int k);

@@ -289,6 +289,7 @@ __global__ __launch_bounds__(1024) void k_line_probe(int n, const int32_t *__res
         host_verdict[3] = est_cc;
         host_verdict[4] = est_cr;
         host_verdict[5] = far_any;
+        host_verdict[6] = B1;   // the constant last column's value: the fill value of a padded model
         host_verdict[0] = mode;
         host_verdict[1] = kdummy;
         host_verdict[2] = suspicious;
@@ -734,10 +735,11 @@ int line_probe_wait(int *mode, int *k, int *suspicious, int *shape3)
     *mode = (int)h[0];
     *k = (int)h[1];
     if (suspicious) *suspicious = (int)h[2];
-    if (shape3) {   // estimated constant columns, estimated constant rows, row 0 too wide for one byte per cell
+    if (shape3) {   // estimated constant columns, estimated constant rows, row 0 too wide for one byte per cell, the last column's value
         shape3[0] = (int)h[3];
         shape3[1] = (int)h[4];
         shape3[2] = (int)h[5];
+        shape3[3] = (int)h[6];
     }
     return TD_OK;
 }
