@@ -196,6 +196,7 @@ int g_shape_max_n = 1 << 20; // TD_SHAPE_MAX_N   largest n the probe runs for
 int g_narrow_price = 1;     // TD_NARROW_PRICE  4-byte cells with a row range <= 2^22: 32-bit prices and labels first (redone in 64 bits if a price reaches 2^27)
 long long g_np_plimit = NP_PLIMIT;   // TD_NP_PLIMIT  (tests) lower price limit of the narrow-price mode in k_assign / k_pcommit
 int g_fuse_t = 2;           // TD_FUSE_T        padded models (dummy requests): one fused transpose + compress pass, no void 1-byte attempt (2: as 1-byte cells + escape when they fit, 1: 4-byte cells, 0: off)
+int g_fuse_spec = 1;        // TD_FUSE_SPEC     the fused pass is speculative (flags read with the final result) when the probe saw a plausible fill value
 int g_fused_rounds = 8;      // TD_FUSED_ROUNDS  bidding rounds launched for a padded model taken by the fused pass
 int g_forest = 1;           // TD_FOREST        cooperative incremental shortest-path forest (k_forest) as the finisher of 4-byte rows
 int g_forest_min_n = 2048;  // TD_FOREST_MIN_N  smallest n it is used for
@@ -237,6 +238,7 @@ void read_tunables()
     if (const char *e = getenv("TD_NARROW_PRICE")) g_narrow_price = atoi(e) != 0;
     if (const char *e = getenv("TD_NP_PLIMIT")) g_np_plimit = std::max(1ll, std::min((long long)NP_PLIMIT, atoll(e)));
     if (const char *e = getenv("TD_FUSE_T")) g_fuse_t = std::max(0, std::min(2, atoi(e)));
+    if (const char *e = getenv("TD_FUSE_SPEC")) g_fuse_spec = atoi(e) != 0;
     if (const char *e = getenv("TD_FUSED_ROUNDS")) g_fused_rounds = std::max(1, std::min(48, atoi(e)));
     if (const char *e = getenv("TD_FOREST")) g_forest = atoi(e) != 0;
     if (const char *e = getenv("TD_FOREST_MIN_N")) g_forest_min_n = std::max(64, atoi(e));
@@ -2854,7 +2856,7 @@ int sv_compress(Solver &sv, int bpc, bool *fits, bool speculate = false)
 }
 
 // padded model: the transposed problem's 4-byte cells straight from the caller's matrix (k_compress_tr)
-int sv_compress_fused(Solver &sv, bool *fits, int64_t *range, bool cells8 = false, int esc_raw = 0)
+int sv_compress_fused(Solver &sv, bool *fits, int64_t *range, bool cells8 = false, int esc_raw = 0, bool nosync = false)
 {
     Ctx &c = ctx();
     const int n = sv.n;
@@ -2881,6 +2883,13 @@ int sv_compress_fused(Solver &sv, bool *fits, int64_t *range, bool cells8 = fals
                                                            cells8 ? 1 : 0);
     }
     TD_HIP(hipGetLastError());
+    if (nosync) {   // speculative like the 1-byte attempt of a square model: the flags come home with the final read-back
+        *fits = true;
+        sv.nconst = -1;
+        sv.nchunks = nchunks;
+        sv.npad = npad;
+        return TD_OK;
+    }
     TD_HIP(hipMemcpyAsync(c.pinned, ctl, 8 * sizeof(int), hipMemcpyDeviceToHost, c.stream));
     TD_HIP(hipStreamSynchronize(c.stream));
     const int *h = (const int *)c.pinned;
@@ -2890,8 +2899,6 @@ int sv_compress_fused(Solver &sv, bool *fits, int64_t *range, bool cells8 = fals
     if (*fits) {
         sv.nchunks = nchunks;
         sv.npad = npad;
-        // the range word is a "did not fit" report for the regular passes: clear it and the flag for the solve
-        TD_HIP(hipMemsetAsync(ctl + CTL_RANGE, 0, 2 * sizeof(int), c.stream));
     }
     return TD_OK;
 }
@@ -3356,8 +3363,8 @@ int sv_readback(Solver &sv, int64_t *total, int64_t *dual, int max_rounds, int *
 {
     Ctx &c = ctx();
     char *pin = (char *)c.pinned;
-    TD_HIP(hipMemcpyAsync(pin, sv.misc.p, CTL_ALL * sizeof(int), hipMemcpyDeviceToHost, c.stream));
-    TD_HIP(hipMemcpyAsync(pin + 1024, (char *)sv.misc.p + 1024, 16, hipMemcpyDeviceToHost, c.stream));
+    static_assert(CTL_ALL * sizeof(int) <= 1024, "the totals sit at byte 1024 of the control block");
+    TD_HIP(hipMemcpyAsync(pin, sv.misc.p, 1024 + 16, hipMemcpyDeviceToHost, c.stream));   // control words + totals: one copy
     TD_HIP(hipStreamSynchronize(c.stream));
     const int *hctl = (const int *)pin;
     if (range_flag) {
@@ -3444,9 +3451,10 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     }
     c.stats[8] = 0;
     int max_rounds = g_max_rounds;
-    bool solved = false, transposed = false, np_failed = false;
+    bool solved = false, transposed = false, np_failed = false, no_fuse = false, fused_spec = false;
     int64_t range_hint = -1;
     sv.defer_const = g_defer_const && !g_solver_eps;
+restart:
     for (int orient = 0; orient < 2 && !solved; orient++) {
     bool want_transpose = false;
     int64_t known_range = transposed ? range_hint : -1;
@@ -3467,6 +3475,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         if (sv.fused_t) {   // cc already holds the transposed problem (k_compress_tr); the same bytes serve both price widths
             fits = true;
             sv.bpc = bpc;
+            if (np_failed) k_fill_i32<<<1, 64, 0, c.stream>>>((int *)sv.misc.p + CTL_FLAG, 2, 0);   // the price-limit flag of the 32-bit attempt
         } else if ((rc = sv_compress(sv, bpc, &fits, spec)))
             return rc;
         if (line_pending) {
@@ -3478,15 +3487,20 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
                 // The probe made the speculative 1-byte pass queued behind it a no-op (its device flag): that attempt
                 // was going to be void — row 0 is too wide for one byte, or the model is padded with dummy requests.
                 const int margin = n / 256 > 32 ? n / 256 : 32;   // the rule of the shape probe (k_init_state), on the probe's estimate
-                if (g_fuse_t && g_shape && !g_solver_eps && shape3[0] >= 16 && shape3[0] - shape3[1] >= margin) {
+                if (g_fuse_t && g_shape && !g_solver_eps && !no_fuse && shape3[0] >= 16 && shape3[0] - shape3[1] >= margin) {
                     bool ff = false;
                     int64_t fr = 0;
+                    // Speculative (no host round trip) when the fill value looks like one: cells in 0 .. fill, 32-bit prices.
+                    // A cell that does not fit raises CTL_FLAG, every later kernel exits, and the final read-back sends the
+                    // call back to the general path (restart).
+                    fused_spec = g_fuse_spec && shape3[3] >= 255 && (int64_t)shape3[3] <= NP_RANGE;
                     // 1-byte cells + escape first ({small range} u {fill}: every reference model of this kind), else 4-byte cells
-                    if (g_fuse_t >= 2 && n <= 65536) {
-                        if ((rc = sv_compress_fused(sv, &ff, &fr, true, shape3[3]))) return rc;
+                    if (g_fuse_t >= 2 && n > 2048 && n <= 65536) {   // a small model is launch-bound: 64 x 1024 tiles leave most CUs idle (tick: 0.465 vs 0.432 ms)
+                        if ((rc = sv_compress_fused(sv, &ff, &fr, true, shape3[3], fused_spec))) return rc;
                         sv.fused8 = ff;
                     }
-                    if (!ff && (rc = sv_compress_fused(sv, &ff, &fr))) return rc;
+                    if (!ff && (rc = sv_compress_fused(sv, &ff, &fr, false, 0, fused_spec))) return rc;
+                    if (fused_spec) fr = shape3[3];
                     if (getenv("TD_DEBUG")) fprintf(stderr, "[td] fused transpose + compress: n=%d fits %d range %lld, %d constant rows\n", n, (int)ff, (long long)fr, sv.nconst);
                     if (ff) {
                         sv.fused_t = true;
@@ -3497,15 +3511,16 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
                         max_rounds = std::min(max_rounds, g_fused_rounds);
                         continue;   // on to the 4-byte widths
                     }
+                    early_check = true;   // the 1-byte attempt is likely void: one look at its flags before the rounds are queued
                     goto compress_pass;   // negative cells or a range beyond 32 bits: the general path, from the 1-byte attempt
                 }
                 if (shape3[2]) {   // row 0 does not fit one byte per cell: skip the 1-byte attempt, the next width measures the range
                     known_range = std::max<int64_t>(known_range, 255);
                     continue;
                 }
+                early_check = true;
                 goto compress_pass;   // only a hint that did not lead anywhere: run the skipped pass
             }
-            early_check = false;
             if (getenv("TD_DEBUG")) fprintf(stderr, "[td] line probe: n=%d verdict %d, %d constant rows, suspicious %d\n", n, mode, kd, susp);
             if (mode) {
                 const int32_t *res = nullptr;
@@ -3659,6 +3674,29 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
                                   hipMemcpyDeviceToHost, c.stream));
         if ((rc = sv_readback(sv, &tot, &dual, max_rounds, (spec || bpc == 5 || bpc == 6) ? &flag : nullptr))) return rc;
         c.stats[1] = warm_rounds;
+        if (sv.fused_t && fused_spec && (flag & 1)) {
+            // the speculative fused pass met a cell outside 0 .. fill (or, for 1-byte cells, outside base .. base + 253):
+            // nothing of it can be kept
+            if (getenv("TD_DEBUG")) fprintf(stderr, "[td] speculative fused pass refused (flag %d): general path\n", flag);
+            if (bpc == 6 && !(flag & ~9)) {   // 1-byte cells did not fit: the same pass with 4-byte cells, checked this time
+                bool ff = false;
+                int64_t fr = 0;
+                sv.fused8 = false;
+                fused_spec = false;
+                if ((rc = sv_compress_fused(sv, &ff, &fr))) return rc;
+                if (ff) {
+                    known_range = fr;
+                    continue;
+                }
+            }
+            no_fuse = true;
+            sv.fused_t = sv.fused8 = false;
+            transposed = false;
+            fused_spec = false;
+            max_rounds = g_max_rounds;
+            early_check = true;
+            goto restart;
+        }
         if (bpc == 5 && flag) {   // a price reached the 32-bit limit: the attempt is void, redo with 64-bit prices
             np_failed = true;
             continue;

@@ -374,6 +374,115 @@ __global__ __launch_bounds__(256) void k_lcms_rows(int n, const int32_t *__restr
     }
 }
 
+// The same for n <= 4096 with ONE WORKGROUP per row: wave w takes the w-th quarter of the columns (all of it loaded at
+// once, <= 16 chunks per lane), so the dependent ballot chain of a 1300-cell row is 6 chunks instead of 21 and a tick's
+// two passes take a third of the time.  Counts per wave and level go through LDS; a row's cells still land in column
+// order (wave-major, then chunk, then lane).  `bad` is raised when a candidate cell lies outside [vmin, vmin + nlev):
+// possible only when the caller HINTED the value range (td_tick knows it from the threshold) — the host then re-runs
+// with the measured range.
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_lcms_rows4(int n, const int32_t *__restrict__ cost, int64_t hi, int vmin, int nlev,
+                                                    int *__restrict__ rowcnt, uint32_t *__restrict__ cells, int *__restrict__ bad, int bad_tag)
+{
+    __shared__ int s_cnt[4][LV_MAX];
+    __shared__ int s_base[4][LV_MAX];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row = blockIdx.x;
+    const int q = (((n + 3) / 4) + 63) / 64 * 64;   // columns per wave (a multiple of 64, <= 1024)
+    const int jlo = w * q;
+    for (int l = lane; l < nlev; l += 64) s_cnt[w][l] = 0;
+    const int32_t *rp = cost + (int64_t)row * n;
+    int lv[LCH];
+    bool oob = false;
+#pragma unroll
+    for (int u = 0; u < LCH; u++) {
+        const int j = jlo + 64 * u + lane;
+        const bool in = 64 * u < q && j < n;
+        const int v = in ? rp[j] : 0;
+        int l = (in && (int64_t)v <= hi) ? v - vmin : -1;
+        if (in && (int64_t)v <= hi && (l < 0 || l >= nlev)) {
+            oob = true;
+            l = -1;
+        }
+        lv[u] = l;
+    }
+    if (__any(oob) && lane == 0) atomicMax(bad, bad_tag);   // tagged with the call's number: the flag never needs clearing
+    // pass 1: counts of this wave per level
+    if (nlev <= 16) {
+#pragma unroll
+        for (int u = 0; u < LCH; u++) {
+            if (64 * u >= q) break;
+            for (int l = 0; l < nlev; l++) {
+                const unsigned long long m = __ballot(lv[u] == l);
+                if (m && lane == 0) s_cnt[w][l] += __popcll(m);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < LCH; u++) {
+            if (64 * u >= q) break;
+            int cur_lv = lv[u];
+            unsigned long long act = __ballot(cur_lv >= 0);
+            while (act) {
+                int cur = cur_lv >= 0 ? cur_lv : INT_MAX;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) cur = min(cur, __shfl_xor(cur, o));
+                const unsigned long long m = __ballot(cur_lv == cur);
+                if (lane == 0) s_cnt[w][cur] += __popcll(m);
+                if (cur_lv == cur) cur_lv = -1;
+                act &= ~m;
+            }
+        }
+    }
+    __syncthreads();
+    if (!SCATTER) {
+        for (int l = tid; l < nlev; l += 256) rowcnt[(size_t)l * n + row] = s_cnt[0][l] + s_cnt[1][l] + s_cnt[2][l] + s_cnt[3][l];
+        return;
+    }
+    for (int l = tid; l < nlev; l += 256) {
+        int b = rowcnt[(size_t)l * n + row];   // offset of (level, row) after the scan
+        for (int ww = 0; ww < 4; ww++) {
+            s_base[ww][l] = b;
+            b += s_cnt[ww][l];
+        }
+    }
+    __syncthreads();
+    // pass 2: scatter in column order
+    if (nlev <= 16) {
+#pragma unroll
+        for (int u = 0; u < LCH; u++) {
+            if (64 * u >= q) break;
+            const int j = jlo + 64 * u + lane;
+            for (int l = 0; l < nlev; l++) {
+                const unsigned long long m = __ballot(lv[u] == l);
+                if (!m) continue;
+                const int base = s_base[w][l];
+                if (lv[u] == l) cells[base + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)row << 16) | (uint32_t)j;
+                if (lane == 0) s_base[w][l] = base + __popcll(m);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < LCH; u++) {
+            if (64 * u >= q) break;
+            const int j = jlo + 64 * u + lane;
+            int cur_lv = lv[u];
+            unsigned long long act = __ballot(cur_lv >= 0);
+            while (act) {
+                int cur = cur_lv >= 0 ? cur_lv : INT_MAX;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) cur = min(cur, __shfl_xor(cur, o));
+                const unsigned long long m = __ballot(cur_lv == cur);
+                const int base = s_base[w][cur];
+                if (cur_lv == cur) cells[base + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)row << 16) | (uint32_t)j;
+                if (lane == 0) s_base[w][cur] = base + __popcll(m);
+                if (cur_lv == cur) cur_lv = -1;
+                act &= ~m;
+            }
+        }
+    }
+}
+
 // exclusive scan of rowcnt[nlev*n] in place (one workgroup), level starts to lvstart[nlev+1]; CH tiles of 1024 are
 // loaded before the serial chain of tile scans starts, so the chain does not wait on memory
 __global__ __launch_bounds__(1024) void k_lcms_scan(int total, int n, int nlev, int *__restrict__ a, int *__restrict__ lvstart)
@@ -579,9 +688,31 @@ __global__ __launch_bounds__(256) void k_lcms_lastmin(int n, const int32_t *__re
 
 }  // namespace
 
+static int lcm_impl(int n, const int32_t *cost, int32_t mask, int32_t threshold, int stop_value_on, int32_t stop_value, int stop_size,
+                    int64_t sum_below, int max_pairs, int32_t *rows, int32_t *cols, int32_t *n_pairs, int64_t *total,
+                    int32_t *last_min, int hint_vmin, int hint_vmax);
+
 extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshold, int stop_value_on,
                       int32_t stop_value, int stop_size, int64_t sum_below, int max_pairs, int32_t *rows,
                       int32_t *cols, int32_t *n_pairs, int64_t *total, int32_t *last_min)
+{
+    return lcm_impl(n, cost, mask, threshold, stop_value_on, stop_value, stop_size, sum_below, max_pairs, rows, cols, n_pairs, total,
+                    last_min, INT_MAX, INT_MIN);
+}
+
+// td_tick knows the candidate cells' value range from the model (0 .. DROP_TIME - 1): no min / max pass, no host round
+// trip for it.  A cell outside the hinted range is detected on the device and the call is redone with the measured range.
+int td::lcm_hinted(int n, const int32_t *cost, int32_t mask, int32_t threshold, int stop_value_on, int32_t stop_value, int stop_size,
+                   int64_t sum_below, int max_pairs, int32_t *rows, int32_t *cols, int32_t *n_pairs, int64_t *total,
+                   int32_t *last_min, int hint_vmin, int hint_vmax)
+{
+    return lcm_impl(n, cost, mask, threshold, stop_value_on, stop_value, stop_size, sum_below, max_pairs, rows, cols, n_pairs, total,
+                    last_min, hint_vmin, hint_vmax);
+}
+
+static int lcm_impl(int n, const int32_t *cost, int32_t mask, int32_t threshold, int stop_value_on, int32_t stop_value, int stop_size,
+                    int64_t sum_below, int max_pairs, int32_t *rows, int32_t *cols, int32_t *n_pairs, int64_t *total,
+                    int32_t *last_min, int hint_vmin, int hint_vmax)
 {
     TD_REQUIRE_INIT();
     Ctx &c = ctx();
@@ -608,7 +739,9 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
     // Java's scan only ever sees cells strictly below big_cost (Simulator.java:529-537)
     const int64_t cand_limit = stop_value_on ? (int64_t)stop_value : (int64_t)INT64_MAX;
     const size_t shm_mask = sizeof(uint32_t) * (size_t)((n + 31) / 32);
-    bool fast = false;
+    bool fast = false, hinted = false;
+    int bad_tag = -1;
+    int *d_bad = (int *)((char *)c.lcm_d.p + 104);   // a candidate cell outside the level range (hinted ranges only)
     if (g_lcm_lists && n >= 64 && n <= 65536) {
         // level lists: candidates are the cells the loop could ever take
         int64_t hi = std::min<int64_t>(cand_limit - 1, (int64_t)mask - 1);
@@ -617,6 +750,13 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
         const int grid = (int)std::min<int64_t>((cellsN + 4095) / 4096, (int64_t)c.n_cu * 4);
         LcmsInfo *d_info = (LcmsInfo *)((char *)c.lcm_d.p + 512);   // one partial per workgroup
         LcmsInfo info;
+        hinted = hint_vmin <= hint_vmax && n <= 4096 && (int64_t)hint_vmax - hint_vmin < LV_MAX;
+        if (hinted) {
+            info.count = cellsN;   // upper bound: sizes the list buffer
+            info.vmin = hint_vmin;
+            info.vmax = (int)std::min<int64_t>(hint_vmax, hi);
+            if (info.vmax < info.vmin) info.vmax = info.vmin;
+        } else {
         {
             ProfScope ps(TD_K_LCM);
             k_lcms_minmax<<<grid, 256, 0, c.stream>>>(n, d_cost, hi, d_info);
@@ -633,6 +773,7 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
                 info.vmin = std::min(info.vmin, pt.vmin);
                 info.vmax = std::max(info.vmax, pt.vmax);
             }
+        }
         }
         if (info.count > 0 && info.count <= (1ll << 28) && (int64_t)info.vmax - info.vmin < LV_MAX) {
             fast = true;
@@ -651,9 +792,23 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
             const size_t shm = sizeof(int) * 2 * (size_t)hsz + sizeof(uint32_t) * 2 * (size_t)nw32;
             ProfScope ps(TD_K_LCM);
             const int rgrid = std::min((n + 3) / 4, c.n_cu * 8);
-            k_lcms_rows<false><<<rgrid, 256, 0, c.stream>>>(n, d_cost, hi, info.vmin, nlev, d_cnt, nullptr);
-            k_lcms_scan<<<1, 1024, 0, c.stream>>>(nlev * n, n, nlev, d_cnt, d_lvstart);
-            k_lcms_rows<true><<<rgrid, 256, 0, c.stream>>>(n, d_cost, hi, info.vmin, nlev, d_cnt, (uint32_t *)c.cc.p);
+            if (n <= 4096) {   // one workgroup per row: a third of the latency on tick-sized models
+                static int s_tag = 0;
+                static const void *s_buf = nullptr;
+                if (s_buf != c.lcm_d.p || s_tag == INT_MAX) {   // a fresh buffer (first use, re-init) or a wrap: start the tags over
+                    TD_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), c.stream));
+                    s_tag = 0;
+                    s_buf = c.lcm_d.p;
+                }
+                bad_tag = ++s_tag;
+                k_lcms_rows4<false><<<n, 256, 0, c.stream>>>(n, d_cost, hi, info.vmin, nlev, d_cnt, nullptr, d_bad, bad_tag);
+                k_lcms_scan<<<1, 1024, 0, c.stream>>>(nlev * n, n, nlev, d_cnt, d_lvstart);
+                k_lcms_rows4<true><<<n, 256, 0, c.stream>>>(n, d_cost, hi, info.vmin, nlev, d_cnt, (uint32_t *)c.cc.p, d_bad, bad_tag);
+            } else {
+                k_lcms_rows<false><<<rgrid, 256, 0, c.stream>>>(n, d_cost, hi, info.vmin, nlev, d_cnt, nullptr);
+                k_lcms_scan<<<1, 1024, 0, c.stream>>>(nlev * n, n, nlev, d_cnt, d_lvstart);
+                k_lcms_rows<true><<<rgrid, 256, 0, c.stream>>>(n, d_cost, hi, info.vmin, nlev, d_cnt, (uint32_t *)c.cc.p);
+            }
             if (shm > 48 * 1024)
                 (void)hipFuncSetAttribute((const void *)k_lcms_greedy<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
             k_lcms_greedy<false><<<1, 1024, shm, c.stream>>>(n, hsz - 1, nlev, info.vmin, (const uint32_t *)c.cc.p, d_lvstart, limit,
@@ -679,13 +834,17 @@ extern "C" int td_lcm(int n, const int32_t *cost, int32_t mask, int32_t threshol
                                             pitch, d_base, 0);
     }
     TD_HIP(hipGetLastError());
-    TD_HIP(hipMemcpyAsync(c.pinned, c.lcm_d.p, sizeof(LcmOut), hipMemcpyDeviceToHost, c.stream));
+    TD_HIP(hipMemcpyAsync(c.pinned, c.lcm_d.p, 128, hipMemcpyDeviceToHost, c.stream));   // LcmOut + the flags behind it
     // host outputs of a tick-sized model: the pair lists ride along into the pinned block (one round trip, no
     // blocking pageable copies); d_rows and d_cols are contiguous (n entries each)
     const bool via_pinned = !is_device_ptr(rows) && !is_device_ptr(cols) && (size_t)8192 + sizeof(int32_t) * 2 * (size_t)n <= c.pinned_cap;
     if (via_pinned)
         TD_HIP(hipMemcpyAsync((char *)c.pinned + 8192, d_rows, sizeof(int32_t) * 2 * (size_t)n, hipMemcpyDeviceToHost, c.stream));
     TD_HIP(hipStreamSynchronize(c.stream));
+    if (hinted && fast && ((const int *)c.pinned)[104 / 4] == bad_tag) {   // the hint was wrong: the lists are void
+        return lcm_impl(n, cost, mask, threshold, stop_value_on, stop_value, stop_size, sum_below, max_pairs, rows, cols, n_pairs, total,
+                        last_min, INT_MAX, INT_MIN);
+    }
     LcmOut o = *(const LcmOut *)c.pinned;
     if (fast && o.last_min == INT_MAX) o.last_min = stop_value_on ? stop_value : mask;   // nothing left to look at
     if (o.n_pairs > 0 && via_pinned) {
@@ -1124,7 +1283,9 @@ extern "C" int td_pool2(int n, const int32_t *from, const int32_t *to, const int
     }
     // The greedy pass over the n (n - 1) ordered pairs: level lists as in td_lcm (pair costs are sums of three
     // distances: a few dozen to ~150 distinct values), walked by k_lcms_greedy<SYM>; the row-scan loop otherwise.
-    bool fast = false;
+    bool fast = false, hinted = false;
+    int bad_tag = -1;
+    int *d_bad = (int *)((char *)c.lcm_d.p + 104);   // a candidate cell outside the level range (hinted ranges only)
     if (g_lcm_lists && n >= 64 && n <= 65536) {
         const int64_t hi = (int64_t)INT_MAX - 1;
         const int64_t cellsN = (int64_t)n * n;

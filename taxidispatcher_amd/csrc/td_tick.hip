@@ -9,6 +9,8 @@
 // over the LCM pair list that td_lcm leaves on the device, and what crosses PCIe per tick is the position arrays
 // in, the pair list / kept indices / row_to_col out (a few KiB).  Host synchronisations per tick: the two inside
 // td_lcm (level-list sizing + result), the one at the end of td_assign.
+#include <limits.h>
+
 #include "td_common.h"
 
 using namespace td;
@@ -138,8 +140,22 @@ extern "C" int td_tick(const int32_t *cab_to, int n_s, const int32_t *dem_from, 
         }
         return put(src, cnt, dst);
     };
-    if ((rc = put_small(cab_to, n_s, d_cab))) return rc;
-    if ((rc = put_small(dem_from, n_d, d_dem))) return rc;
+    if (n_s > 0 && n_d > 0 && !is_device_ptr(cab_to) && !is_device_ptr(dem_from) && c.pin_in && sizeof(int32_t) * 2 * (size_t)n <= 32768) {
+        // both position arrays in ONE staged copy (d_cab and d_dem are n apart)
+        const size_t bytes = sizeof(int32_t) * ((size_t)n + n_d), need = (bytes + 255) & ~(size_t)255;
+        if (c.pin_in_off + need > c.pin_in_cap) {
+            TD_HIP(hipStreamSynchronize(c.stream));
+            c.pin_in_off = 0;
+        }
+        int32_t *slot = (int32_t *)((char *)c.pin_in + c.pin_in_off);
+        c.pin_in_off += need;
+        memcpy(slot, cab_to, sizeof(int32_t) * (size_t)n_s);
+        memcpy(slot + n, dem_from, sizeof(int32_t) * (size_t)n_d);
+        TD_HIP(hipMemcpyAsync(d_cab, slot, bytes, hipMemcpyHostToDevice, c.stream));
+    } else {
+        if ((rc = put_small(cab_to, n_s, d_cab))) return rc;
+        if ((rc = put_small(dem_from, n_d, d_dem))) return rc;
+    }
     const int32_t *d_dist = dist;
     if (dist && !is_device_ptr(dist)) {
         int32_t *dd = d_pos + 4 * (size_t)n;
@@ -153,7 +169,12 @@ extern "C" int td_tick(const int32_t *cab_to, int n_s, const int32_t *dem_from, 
     int32_t last_min = fill;
     if (stop_size >= 0 && stop_size < n) {
         // Simulator.java:523-549: stop on big_cost or when MAX_NON_LCM rows are left; dummies are never summed
-        if ((rc = td_lcm(n, d_a, fill, -1, 1, fill, stop_size, (int64_t)fill, n, lcm_rows, lcm_cols, &k, &lcm_total, &last_min))) return rc;
+        // every real cell of a thresholded model lies in 0 .. threshold - 1 (distances are not negative): the level lists
+        // are laid out without a min / max pass; a table with a negative distance is caught on the device and redone
+        const bool hint = threshold >= 1 && threshold <= 256;
+        if ((rc = td::lcm_hinted(n, d_a, fill, -1, 1, fill, stop_size, (int64_t)fill, n, lcm_rows, lcm_cols, &k, &lcm_total, &last_min,
+                                 hint ? 0 : INT_MAX, hint ? threshold - 1 : INT_MIN)))
+            return rc;
     }
     *n_pairs = k;
     if (lcm_last_min) *lcm_last_min = last_min;
