@@ -163,6 +163,7 @@ int g_max_rounds = 12;      // TD_MAX_ROUNDS    bidding rounds launched (converg
 int g_tie_evict = 1;        // TD_TIE_EVICT     rounds >= 1: a tie on owned columns still takes the column
 int g_lds_rounds = 1;       // TD_LDS_ROUNDS    first rounds that stage the price vector in LDS
 int g_lds_grid = 1;         // TD_LDS_GRID      workgroups per CU of the LDS-staged bidding kernel
+int g_row_loop = 5;         // TD_ROW_LOOP      from this round on k_bid_row loops over the rows with a fixed grid
 int g_row_rounds = 2;       // TD_ROW_ROUNDS    from this round on: one workgroup per row (k_bid_row)
 int g_cgrid = 4;            // TD_CGRID         workgroups per CU of the compress pass
 int g_creg = 1;             // TD_CREG          register-resident compress kernel
@@ -214,6 +215,7 @@ void read_tunables()
     if (const char *e = getenv("TD_TIE_EVICT")) g_tie_evict = atoi(e) != 0;
     if (const char *e = getenv("TD_LDS_ROUNDS")) g_lds_rounds = std::max(0, atoi(e));
     if (const char *e = getenv("TD_SAP8")) g_sap8 = atoi(e) != 0;
+    if (const char *e = getenv("TD_ROW_LOOP")) g_row_loop = std::max(0, atoi(e));
     if (const char *e = getenv("TD_ROW_ROUNDS")) g_row_rounds = std::max(0, atoi(e));
     if (const char *e = getenv("TD_CGRID")) g_cgrid = std::max(1, atoi(e));
     if (const char *e = getenv("TD_CREG")) g_creg = atoi(e) != 0;
@@ -2936,7 +2938,10 @@ int sv_bid_t(Solver &sv, int r, unsigned long long *keys)
         k_bid<CT, true><<<grid, 1024, lds_prices, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
                                                               (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict, 1, 0, tied);
     } else if (r >= g_row_rounds) {
-        k_bid_row<CT><<<std::min(nrows, c.n_cu * 8), 256, 0, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
+        // one workgroup per row while a round still has hundreds of bidders (perf.jl: 9.5 us against 10.4 with the loop),
+        // a grid-stride loop over the rows from round TD_ROW_LOOP on, where a handful is left and spawning 16 384
+        // workgroups to see that their rows are assigned costs more than the round's work
+        k_bid_row<CT><<<(r < g_row_loop) ? nrows : std::min(nrows, c.n_cu * 8), 256, 0, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
                                                    (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict);
     } else {
         k_bid<CT, false><<<(nrows + 3) / 4, 256, 0, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
