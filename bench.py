@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=16384)
-    ap.add_argument("--workload", default="g1", choices=["g1", "g2", "g3", "tick"])
+    ap.add_argument("--workload", default="g1", choices=["g1", "g2", "g3", "tick", "pool"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the sharded leg even with one rank (exercises RCCL + the shard API on 1 GPU)")
@@ -227,6 +227,98 @@ def single_gpu_reference(n, torch, ffi, reps=3):
     return {"ms_per_step": 1e3 * min(ts[1:]), "total_cost": int(tot.value)}
 
 
+# name, seed, n, max_wait, loss choices (the generator of tests/golden/make_pool_fixtures.py, gendemand.py:10 trips), pool sizes.
+# pool_n.c keeps at most MAX_ARR = 10 000 happy plans per child in a static array WITHOUT a bounds check: n = 600, k = 3 has
+# 17 154 for one child (k = 4: 310 944) and the reference binary dies with SIGSEGV on it.  So the reference binary is timed on
+# the committed fixture instances (tests/golden/pool_n/<name>_demand.csv, the largest it can run), the bench sizes run
+# on the GPU and on the oracle's port only.
+POOL_CASES = [
+    ("n600", 11, 600, 2, [1, 10, 25], (2, 3, 4)),
+    ("n2000", 12, 2000, 1, [1, 5], (2, 3)),
+]
+POOL_FIXTURE_CASES = [("c300", (2, 3)), ("d200", (4,)), ("f400", (3,)), ("b120", (2, 3, 4))]
+
+
+def pool_demand(seed, n, max_wait, losses):
+    rng = np.random.default_rng(seed)
+    frm = rng.integers(0, 50, n)
+    diff = rng.integers(1, 9, n) * rng.choice([-1, 1], n)
+    to = np.clip(frm + diff, 0, 49)
+    to = np.where(to == frm, np.where(frm > 0, frm - 1, 1), to)
+    wait = rng.integers(0, max_wait + 1, n)
+    loss = rng.choice(losses, n)
+    return np.stack([np.arange(n), frm, to, wait, loss], 1)
+
+
+def pool_workload(td, reps, cpu_seconds):
+    """f-4 (pool_n.c:101-242 / findpool.c:122-176): pools of k = 2, 3, 4 passengers over findpool.c's 8 first-pick-up
+    slices (8 td_pool_n calls) + the merge (td_pool_merge), timed per (n, k); beside it the oracle's single-thread C
+    restatement of the same 8 children + merge on this box's host core (bounded), and — where the file exists — the
+    wall time of the REFERENCE binary oracle/_ref/pool_n measured in the build container
+    (tests/golden/pool_n/reference_timing.json, made by tests/golden/time_pool_reference.py)."""
+    import torch
+    from oracle import oracle
+    ref_path = os.path.join(ROOT, "tests", "golden", "pool_n", "reference_timing.json")
+    ref = json.load(open(ref_path)) if os.path.exists(ref_path) else {}
+    out = {}
+    cases = [(name, pool_demand(seed, n, mw, losses), ks) for name, seed, n, mw, losses, ks in POOL_CASES]
+    for name, ks in POOL_FIXTURE_CASES:
+        fp = os.path.join(ROOT, "tests", "golden", "pool_n", name + "_demand.csv")
+        if os.path.exists(fp):
+            cases.append((name, np.loadtxt(fp, delimiter=",", dtype=np.int64), ks))
+    for name, d, ks in cases:
+        n = int(d.shape[0])
+        frm, to, wait, loss = (np.ascontiguousarray(d[:, c]).astype(np.int32) for c in (1, 2, 3, 4))
+        for k in ks:
+            def gpu_once():
+                lists, happy = [], 0
+                for child in range(8):
+                    lst, nh = td.find_pool_n(k, d, child=child, children=8)
+                    lists.append(lst)
+                    happy += nh
+                return td.merge_pools(k, n, lists), happy
+            merged, happy = gpu_once()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                merged, happy = gpu_once()
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / reps
+            # CPU port: the same 8 slices + the same merge rule, one thread, bounded
+            t_budget = time.perf_counter() + cpu_seconds
+            creps, spent, cm = 0, 0.0, None
+            step = n // 8 + 1
+            while True:
+                t1 = time.perf_counter()
+                lists = []
+                for child in range(8):
+                    a = step * child
+                    lst, _ = oracle.pool_n(k, frm, to, wait, loss, None, a, max(a, min(n, a + step)), cap=4000000)
+                    lists.append(lst.tolist())
+                allp = [r for lst in lists for r in lst]
+                if k == 4:
+                    allp = sorted(allp, key=lambda r: r[8])
+                used, kept = set(), []
+                for r in allp:
+                    if any(x in used for x in r[:k]):
+                        continue
+                    used.update(r[:k])
+                    kept.append(r)
+                cm = kept
+                spent += time.perf_counter() - t1
+                creps += 1
+                if creps >= 8 or time.perf_counter() + spent / creps > t_budget:
+                    break
+            key = "%s_k%d" % (name, k)
+            out[key] = {"n": n, "k": k, "happy_plans": int(happy), "pools": int(len(merged)), "gpu_ms": ms,
+                        "requests_per_s": n / (ms * 1e-3), "cpu_port_ms": 1e3 * spent / creps, "cpu_port_reps": creps,
+                        "pools_match_cpu_port": bool(np.array_equal(np.asarray(merged), np.asarray(cm, np.int32).reshape(-1, 2 * k + 1)))}
+            if key in ref:
+                out[key]["reference_binary_ms_build_container"] = ref[key]["wall_ms"]
+                out[key]["reference_binary_plans"] = ref[key].get("plans")
+    return out
+
+
 def cpu_baseline_tick(seconds):
     from oracle import oracle
     rng = np.random.default_rng(1)
@@ -363,6 +455,19 @@ def main():
     td.set_line_metric(args.line_metric == "on")
     # the library runs on its own stream; the timed region is bracketed by device-wide synchronisation
 
+    if args.workload == "pool":
+        res = pool_workload(td, max(1, min(args.steps, 20)), 0.0 if args.no_cpu_baseline else min(args.cpu_seconds, 4.0))
+        head = res["n600_k4"]
+        line = {"metric": "pool requests/sec (pools of 4, 8 first-pick-up slices + merge)", "value": head["requests_per_s"],
+                "unit": "requests/s", "n_gpus": 1, "steps": max(1, min(args.steps, 20)), "warmup": 1, "ms_per_step": head["gpu_ms"],
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 / f64 happiness test", "data": "synthetic",
+                "config": {"workload": "pool_n.c:101-242 fan-out of findpool.c:122-176: n = 600 requests, pools of 4 (all sizes in `pool`)"},
+                "pool": res,
+                "cpu_baseline": {"value": 600.0 / (head["cpu_port_ms"] * 1e-3), "unit": "requests/s", "cores": 1, "kind": "port",
+                                 "sample": "oracle_pool_n (oracle/td_oracle.c) over the same 8 slices + the merge rule, n = 600, k = 4, %d repetitions"
+                                           % head["cpu_port_reps"], "cpu_model": cpu_model()}}
+        print(json.dumps(line), flush=True)
+        return
     if args.workload == "tick":
         wl = TickWorkload(1 + rank, td)
         args.n = wl.n
@@ -505,6 +610,12 @@ def main():
             except Exception as e:
                 extras[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         td.set_line_metric(True)
+        try:   # f-4: pools of 2 - 4 passengers, fan-out + merge (details: --workload pool)
+            pr = pool_workload(td, 3, 0.5)
+            extras["pool_fanout_merge"] = {k: {f: v[f] for f in ("gpu_ms", "cpu_port_ms", "happy_plans", "pools", "pools_match_cpu_port",
+                                                                "reference_binary_ms_build_container") if f in v} for k, v in pr.items()}
+        except Exception as e:
+            extras["pool_fanout_merge"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         line["other_workloads"] = extras
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.workload, n, args.cpu_seconds)

@@ -194,6 +194,8 @@ TD_API int td_pool2(int n, const int32_t *from, const int32_t *to, const int32_t
  *   order (stable by cost, de-duplicated);  n_happy: happy plans before de-duplication;  max_happy:
  *   capacity of the plan buffer (<= 0: 4 Mi plans; TD_ERANGE when exceeded — the reference's
  *   pool[10000] simply overflows there).
+ *   k = 2, 3 or 4 passengers (TD_EINVAL otherwise: with k = 1 the reference's duplicate test compares its 4 padded slots
+ *   and keeps a single pool, which is not reproduced).
  */
 TD_API int td_pool_n(int k, int n, const int32_t *from, const int32_t *to, const int32_t *max_wait,
                      const int32_t *max_loss, const int32_t *dist, int S, int first0, int first1,

@@ -166,6 +166,59 @@ __global__ __launch_bounds__(256) void k_pooln_enum(int n, const int32_t *__rest
     }
 }
 
+// Pools of FOUR, balanced: one thread per (first, second, third pick-up) — the slice x n x n index space as the grid —
+// walks the fourth pick-up.  With one thread per (first, second) pair the two inner loops are n^2 long for the few
+// pairs that pass the wait rule and empty for the rest: at n = 600 one child took 56 ms with most lanes idle.  Here a
+// whole workgroup leaves at once when (first, second) fails (it is uniform), the survivors' loops are n long, and the
+// happy plans of a wave are appended with ONE atomic per wave and drop-off order instead of one per plan.
+__global__ __launch_bounds__(256) void k_pooln_enum4(int n, const int32_t *__restrict__ from, const int32_t *__restrict__ to,
+                                                     const int32_t *__restrict__ wait, const int32_t *__restrict__ loss,
+                                                     const int32_t *__restrict__ dist, int S, int first0, int first1,
+                                                     unsigned long long cap, unsigned long long *__restrict__ keys,
+                                                     PnCtl *__restrict__ ctl)
+{
+    int p[4];
+    p[0] = first0 + blockIdx.z;
+    p[1] = blockIdx.y;
+    if (p[0] >= first1 || p[1] == p[0] || 0 > wait[p[0]]) return;
+    const int d01 = pn_d(dist, S, from[p[0]], from[p[1]]);
+    if (d01 > wait[p[1]]) return;   // pool_n.c:177-178, uniform over the workgroup
+    const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p2 >= n || p2 == p[0] || p2 == p[1]) return;
+    const int d012 = d01 + pn_d(dist, S, from[p[1]], from[p2]);
+    if (d012 > wait[p2]) return;
+    p[2] = p2;
+    const unsigned long long nn = (unsigned long long)n;
+    const int lane = threadIdx.x & 63;
+    const int f2 = from[p2];
+    for (int p3 = 0; p3 < n; p3++) {
+        if (p3 == p[0] || p3 == p[1] || p3 == p2) continue;
+        if (d012 + pn_d(dist, S, f2, from[p3]) > wait[p3]) continue;
+        p[3] = p3;
+        for (int qi = 0; qi < 24; qi++) {
+            int q[4];
+            pn_perm(4, qi, q);
+            int cost = 0;
+            const bool happy = pn_check<4>(p, q, from, to, loss, dist, S, &cost);
+            const unsigned long long m = __ballot(happy);   // the lanes that are here AND happy
+            if (!m) continue;
+            unsigned long long base = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) base = atomicAdd(&ctl->happy, (unsigned long long)__popcll(m));
+            base = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(base >> 32), leader) << 32) |
+                   (unsigned long long)(uint32_t)__shfl((int)(uint32_t)base, leader);
+            if (happy) {
+                if (cost > PN_MAXCOST || cost < 0) atomicOr(&ctl->err, 1);
+                const unsigned long long idx = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                if (idx < cap) {
+                    const unsigned long long seq = ((((unsigned long long)p[0] * nn + p[1]) * nn + p2) * nn + p3) * 24ull + (unsigned long long)qi;
+                    keys[idx] = ((unsigned long long)cost << PN_SEQ_BITS) | seq;
+                }
+            }
+        }
+    }
+}
+
 // decode the requests of the plan behind sorted key number i
 template <bool FROM_KEY>
 __device__ __forceinline__ void pn_requests(int k, int n, unsigned long long key, const int32_t *recs, int *c)
@@ -351,7 +404,9 @@ extern "C" int td_pool_n(int k, int n, const int32_t *from, const int32_t *to, c
 {
     TD_REQUIRE_INIT();
     Ctx &c = ctx();
-    if (k < 1 || k > 4) return fail(TD_EINVAL, "pool size %d (1..4)", k);
+    // k = 1 is refused on purpose: pool_n.c / findpool.c compare MAX_IN_POOL = 4 slots when they drop duplicates, so with
+    // one passenger the padding makes every later plan a duplicate of the first — not a result worth reproducing
+    if (k < 2 || k > 4) return fail(TD_EINVAL, "pool size %d (2..4)", k);
     if (n < 0 || n > PN_MAXN) return fail(TD_EINVAL, "n=%d (at most %d requests; the reference's MAX_DEMAND is 2000)", n, PN_MAXN);
     if (!n_pools || (max_pools > 0 && !pools)) return fail(TD_EINVAL, "null output");
     if (dist && S <= 0) return fail(TD_EINVAL, "dist given but S=%d", S);
@@ -394,7 +449,13 @@ extern "C" int td_pool_n(int k, int n, const int32_t *from, const int32_t *to, c
             case 1: TD_PN(1); break;
             case 2: TD_PN(2); break;
             case 3: TD_PN(3); break;
-            default: TD_PN(4); break;
+            default:
+                if (n <= 65535 && first1 - first0 <= 65535)
+                    k_pooln_enum4<<<dim3((n + 255) / 256, n, first1 - first0), 256, 0, c.stream>>>(
+                        n, d_arr[0], d_arr[1], d_arr[2], d_arr[3], (const int32_t *)d_dist, S, first0, first1, (unsigned long long)max_happy, keys, ctl);
+                else
+                    TD_PN(4);
+                break;
         }
 #undef TD_PN
         TD_HIP(hipGetLastError());
@@ -419,7 +480,7 @@ extern "C" int td_pool_merge(int k, int n_requests, int n_in, const int32_t *poo
 {
     TD_REQUIRE_INIT();
     Ctx &c = ctx();
-    if (k < 1 || k > 4 || n_requests < 0 || n_requests > PN_MAXN || n_in < 0) return fail(TD_EINVAL, "bad arguments to td_pool_merge");
+    if (k < 2 || k > 4 || n_requests < 0 || n_requests > PN_MAXN || n_in < 0) return fail(TD_EINVAL, "bad arguments to td_pool_merge (pool size 2..4)");
     if (!n_out || (n_in && !pools_in) || (max_pools > 0 && !pools_out)) return fail(TD_EINVAL, "null array");
     *n_out = 0;
     if (n_in == 0 || max_pools <= 0) return TD_OK;

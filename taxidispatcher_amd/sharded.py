@@ -387,28 +387,58 @@ def assign_sharded(cost_rows, n, want_dual=False, rounds=DEFAULT_ROUNDS, dist=No
         sh.close()
 
 
-def pool_fanout(k, demand, dist, children=8, finder=None, merger=None):
+def pool_fanout(k, demand, dist, children=8, finder=None, merger=None, timeout=60.0):
     """findpool.c's 8-way fan-out mapped to GPUs: child t (a first-pick-up slice, pool_n.c:243-246)
-    runs on rank t % world, the lists travel to rank 0 (all_gather_object: a few KiB), rank 0 merges
-    (findpool.c:73-98,166-172) and broadcasts the result.  No data-path collective besides that.
-    `finder(k, demand, child)` -> records, `merger(k, n, lists)` -> records default to the GPU
-    entry points; the gloo test injects host models."""
+    runs on rank t % world, the lists travel to rank 0, rank 0 merges (findpool.c:73-98,166-172) and
+    hands the result back.  No data-path collective: like findpool.c, which polls its children's flag
+    files and gives up after 60 s (findpool.c:149-169 "ERROR: not all threads have returned results"),
+    the lists and the result go through the process group's key-value store (a few KiB per rank) and
+    every wait has `timeout` seconds — a rank that died or hangs makes the others raise TdError naming
+    it instead of blocking in a collective for ever.
+    `finder(k, demand, child)` -> records, `merger(k, n, lists)` -> records default to the GPU entry
+    points; the gloo test injects host models."""
+    import datetime
+    import pickle
     if finder is None or merger is None:
         from . import dispatch
         finder = finder or (lambda kk, dd, child: dispatch.find_pool_n(kk, dd, child=child, children=children)[0])
         merger = merger or dispatch.merge_pools
     world, rank = dist.get_world_size(), dist.get_rank()
+    from torch.distributed import distributed_c10d as c10d
+    store = c10d._get_default_store()
+    pool_fanout._seq = getattr(pool_fanout, "_seq", 0) + 1      # every rank makes the same calls in the same order
+    key = "td_pool_fanout/%d/" % pool_fanout._seq
     mine = {t: np.asarray(finder(k, demand, t)).reshape(-1, 2 * k + 1).tolist() for t in range(children) if t % world == rank}
-    gathered = [None] * world
-    dist.all_gather_object(gathered, mine)
-    lists = {}
-    for g in gathered:
-        lists.update(g)
-    out = [None]
+    store.set(key + "r%d" % rank, pickle.dumps(mine))
+    limit = datetime.timedelta(seconds=float(timeout))
     if rank == 0:
-        out[0] = np.asarray(merger(k, len(demand), [lists[t] for t in range(children)])).reshape(-1, 2 * k + 1).tolist()
-    dist.broadcast_object_list(out, src=0)
-    return np.asarray(out[0], np.int32).reshape(-1, 2 * k + 1)
+        keys = [key + "r%d" % r for r in range(world)]
+        try:
+            store.wait(keys, limit)
+        except Exception:
+            missing = [r for r in range(world) if not store.check([key + "r%d" % r])]
+            store.set(key + "result", pickle.dumps(("error", missing)))
+            raise _ffi.TdError("pool fan-out: rank(s) %s did not deliver their slices within %.0f s (findpool.c:165-168 gives up the "
+                               "same way)" % (missing, float(timeout)))
+        lists = {}
+        for kk in keys:
+            lists.update(pickle.loads(store.get(kk)))
+        out = np.asarray(merger(k, len(demand), [lists[t] for t in range(children)])).reshape(-1, 2 * k + 1).tolist()
+        store.set(key + "result", pickle.dumps(("ok", out)))
+        for kk in keys:
+            try:
+                store.delete_key(kk)
+            except Exception:
+                pass
+    else:
+        try:
+            store.wait([key + "result"], limit + datetime.timedelta(seconds=5))
+        except Exception:
+            raise _ffi.TdError("pool fan-out: rank 0 did not hand the merged pools back within %.0f s" % (float(timeout) + 5))
+        status, out = pickle.loads(store.get(key + "result"))
+        if status != "ok":
+            raise _ffi.TdError("pool fan-out: rank(s) %s did not deliver their slices within %.0f s" % (out, float(timeout)))
+    return np.asarray(out, np.int32).reshape(-1, 2 * k + 1)
 
 
 # ----------------------------------------------------------------------------------------

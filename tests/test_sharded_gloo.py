@@ -124,6 +124,55 @@ def _pool_worker(rank, world, port, name, k, q):
     dist.destroy_process_group()
 
 
+def _pool_dead_rank_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+    import pool_fixtures as pf
+    from oracle import oracle
+    from taxidispatcher_amd import _ffi, sharded
+    d, _ = pf.load("a40", 2)
+    n = len(d)
+
+    def finder(kk, dd, child):
+        a, b = pf.child_slice(n, child)
+        return oracle.pool_n(kk, dd[:, 1], dd[:, 2], dd[:, 3], dd[:, 4], None, a, b)[0]
+
+    if rank == world - 1:          # the "dead" rank: never calls the fan-out (findpool.c: a child that never raises its flag)
+        time.sleep(6)
+        q.put((rank, "silent"))
+    else:
+        t0 = time.time()
+        try:
+            sharded.pool_fanout(2, d, dist, finder=finder, merger=lambda kk, nn, lists: pf.merge_restatement(kk, lists), timeout=2.0)
+            q.put((rank, "returned"))
+        except _ffi.TdError as e:
+            q.put((rank, "TdError after %.1f s: %s" % (time.time() - t0, e)))
+    # no barrier: the silent rank must not be waited for by a collective either
+
+
+def test_pool_fanout_gives_up_on_a_dead_rank():
+    """findpool.c:149-169: the parent waits 60 s for its children's flags, then 'ERROR: not all threads have returned
+    results'.  pool_fanout's waits are bounded the same way: with one rank silent the others raise within the timeout
+    (2 s here) and name it, instead of blocking in a collective."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pool_dead_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert outs[2] == "silent"
+    for r in (0, 1):
+        assert outs[r].startswith("TdError after"), outs[r]
+        assert float(outs[r].split()[2]) < 12.0
+    assert "[2]" in outs[0]
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_pool_fanout_over_ranks(world):
     """f-4 fan-out (findpool.c's 8 children) over `world` ranks: every rank ends with the merge of
