@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--sharded-n", type=int, default=65536,
                     help="with --gpus > 1: also solve ONE instance of this size row-sharded over all ranks "
                          "(BASELINE configs[3]); 0 disables")
+    ap.add_argument("--shard-builder", default="gen", choices=["gen", "cost", "both"],
+                    help="sharded leg: how a rank fills its rows — td_gen_uniform's row window, td_cost_build_rows, or both (two timings)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--multi-mode", default="sharded", choices=["sharded", "replicas"],
                     help="headline of a multi-GPU run: the row-sharded single instance (configs[3]) or replicas")
@@ -161,7 +163,7 @@ def kernel_profile(wl, ffi, reps):
     return out
 
 
-def sharded_leg(n, world, rank, torch, dist, ffi, steps, warmup):
+def sharded_leg(n, world, rank, torch, dist, ffi, steps, warmup, builder="gen"):
     """BASELINE configs[3]: ONE n x n perf.jl instance row-sharded over all ranks.  A step = every
     rank writes its row block in place (td_gen_uniform with its row window: the synthetic stand-in
     for the shard-local cost build, td_cost_build_rows) + the sharded solve: one RCCL MAX all-reduce
@@ -173,8 +175,20 @@ def sharded_leg(n, world, rank, torch, dist, ffi, steps, warmup):
     sh = sharded.HipShard(n, row0, nrows, rows)   # workspace allocated once, reused by every solve
     total = None
 
+    if builder == "cost":
+        # the shard-local COST BUILD itself (td_cost_build_rows, greedy_opt.py:86-99 over a general S x S table with
+        # perf.jl's value range 10..40): positions and table are replicated, every rank builds its own rows
+        rng = np.random.default_rng(5)
+        S = 1000
+        table = torch.from_numpy(rng.integers(10, 41, (S, S)).astype(np.int32)).cuda()
+        cab = torch.from_numpy(rng.integers(0, S, n).astype(np.int32)).cuda()
+        dem = torch.from_numpy(rng.integers(0, S, n).astype(np.int32)).cuda()
+
     def step():
-        if nrows:
+        if nrows and builder == "cost":
+            ffi.check(ffi.lib().td_cost_build_rows(cab.data_ptr(), None, n, dem.data_ptr(), None, n, table.data_ptr(), S, 250000, -1, 0,
+                                                   row0, nrows, rows.data_ptr()))
+        elif nrows:
             ffi.check(ffi.lib().td_gen_uniform(n, 7, 10, 40, row0, nrows, rows.data_ptr()))
         return sharded.solve_sharded(sh, dist)[1]
 
@@ -201,9 +215,9 @@ def sharded_leg(n, world, rank, torch, dist, ffi, steps, warmup):
         sh.close()
     del rows
     torch.cuda.empty_cache()
-    return {"workload": "g1 N=%d, ONE instance row-sharded over %d GPUs (%d rows each), shard-local cost write + "
+    return {"workload": "g1 N=%d, ONE instance row-sharded over %d GPUs (%d rows each), shard-local %s + "
                         "RCCL MAX all-reduce of %d KiB keys per bidding round, finisher on rank 0 over hipIpc-mapped "
-                        "shards" % (n, world, nrows, n * 8 // 1024),
+                        "shards" % (n, world, nrows, "cost build (td_cost_build_rows, 1000-stand table)" if builder == "cost" else "cost write", n * 8 // 1024),
             "n": n, "ms_per_step": 1e3 * dt / steps, "assignments_per_s": n * steps / dt,
             "total_cost": int(total), "optimal": bool(total == 10 * n), "scaling": "strong", "seconds": dt}
 
@@ -570,7 +584,11 @@ def main():
             del wl.cost
             torch.cuda.empty_cache()
             try:
-                shard_res = sharded_leg(args.sharded_n, world, rank, torch, dist, ffi, max(1, args.steps), args.warmup)
+                shard_res = sharded_leg(args.sharded_n, world, rank, torch, dist, ffi, max(1, args.steps), args.warmup,
+                                        "cost" if args.shard_builder == "cost" else "gen")
+                if args.shard_builder == "both":
+                    extra = sharded_leg(args.sharded_n, world, rank, torch, dist, ffi, max(1, args.steps), args.warmup, "cost")
+                    shard_res["with_td_cost_build_rows"] = {k: extra[k] for k in ("ms_per_step", "assignments_per_s", "total_cost", "workload")}
                 if rank == 0:
                     single_ref = single_gpu_reference(args.sharded_n, torch, ffi)
                     shard_res["single_gpu_ms_per_step"] = single_ref["ms_per_step"]

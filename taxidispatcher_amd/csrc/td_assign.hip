@@ -188,6 +188,7 @@ int g_warm_min_range = 256; // TD_WARM_MIN_RANGE rows narrower than this are nev
 int g_warm_minfree = 32;    // TD_WARM_MINFREE  free rows after the eps = 0 rounds below which the finisher is cheaper
 int g_sapx = 1;             // TD_SAPX          cooperative multi-workgroup serial finisher (k_sapx)
 int g_sapx_min = 8;         // TD_SAPX_MIN      fewest workgroups (256 chunks each) for which it is used
+int g_sapx_slim_chunks = INT_MAX; // TD_SAPX_SLIM  1- / 2-byte rows with at least this many 16-byte chunks: 64-thread column slices in k_sapx.  OFF: measured at n = 65 536 (perf.jl rows, 7 searches, 14 steps) 64 slim workgroups take 1.41 ms against 0.71 ms for 16 wide ones — the barrier and the publish phase grow with the workgroup count faster than the relax shrinks
 int g_sapx_rows = 24;       // TD_SAPX_ROWS     ... half of that when at least this many rows are left for it
 int g_sap512 = 1;           // TD_SAP512        512-thread generic finisher (double register budget) for n <= 8192
 int g_psap_worth = 4;       // TD_PSAP_WORTH    rows a batch must commit on average for another group to be launched
@@ -233,6 +234,7 @@ void read_tunables()
     if (const char *e = getenv("TD_WARM_MIN_RANGE")) g_warm_min_range = std::max(1, atoi(e));
     if (const char *e = getenv("TD_WARM_MINFREE")) g_warm_minfree = std::max(1, atoi(e));
     if (const char *e = getenv("TD_SAPX_MIN")) g_sapx_min = std::max(1, atoi(e));
+    if (const char *e = getenv("TD_SAPX_SLIM")) g_sapx_slim_chunks = std::max(64, atoi(e));
     if (const char *e = getenv("TD_SAPX_ROWS")) g_sapx_rows = std::max(1, atoi(e));
     if (const char *e = getenv("TD_PSAP_WORTH")) g_psap_worth = std::max(1, atoi(e));
     if (const char *e = getenv("TD_SPECULATE")) g_speculate = atoi(e) != 0;
@@ -3125,12 +3127,15 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
 #define TD_SX_TX 128
 #endif
         constexpr int TXsel = (sizeof(CT) == 4) ? TD_SX_TX : 256;
-        const int KX = (nchunks + TXsel - 1) / TXsel;
+        // narrow cells of a very wide matrix (1-byte rows at n = 65 536: 4096 chunks): 64-thread column slices, so that 64
+        // CUs instead of 16 pull the published rows (a step of ~70 rows x 64 KiB took 27 us through 16 CUs)
+        const bool slim = sizeof(CT) < 4 && nchunks >= g_sapx_slim_chunks;
+        const int KX = slim ? (nchunks + 63) / 64 : (nchunks + TXsel - 1) / TXsel;
         const bool lean8 = IsLean8<CT>::value && CH == 1 && g_sap8;
         bool launched_x = false;
         // from 8 x 256 chunks on always; from 4 x 256 on when many rows are left (|a-b| n = 6000: 190 -> 109 ms with 62 rows;
         // uniform 0..10^6 n = 4096 with 10 rows: 9.8 -> 12.1 ms, so not for a handful)
-        const bool big = KX * TXsel >= g_sapx_min * 256 || (KX * TXsel >= g_sapx_min * 128 && nfree_left >= g_sapx_rows);
+        const bool big = slim || KX * TXsel >= g_sapx_min * 256 || (KX * TXsel >= g_sapx_min * 128 && nfree_left >= g_sapx_rows);
         if (g_sapx && !lean8 && big && KX <= SX_KMAX) {
             Ctx &c = ctx();
             using PT = typename Tr<CT>::PT;
@@ -3146,8 +3151,14 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
             void *kargs[] = {&a_n, &a_nch, &a_tab, &a_pk, &a_owner, &a_r2c, &a_pred, &a_list, &a_ctl, &a_sh};
             // 4-byte cells: 4 row groups per workgroup (1024 threads, 4 waves per SIMD in the relax phase)
             constexpr int NGsel = (sizeof(CT) == 4) ? TD_SX_NG : 1;
-            const hipError_t le = hipLaunchCooperativeKernel((const void *)k_sapx<CT, TXsel, NGsel>, dim3(KX), dim3(TXsel * NGsel), kargs, 0,
-                                                             c.stream);
+            hipError_t le;
+            if constexpr (sizeof(CT) < 4) {
+                if (slim)
+                    le = hipLaunchCooperativeKernel((const void *)k_sapx<CT, 64, 1>, dim3(KX), dim3(64), kargs, 0, c.stream);
+                else
+                    le = hipLaunchCooperativeKernel((const void *)k_sapx<CT, TXsel, NGsel>, dim3(KX), dim3(TXsel * NGsel), kargs, 0, c.stream);
+            } else
+                le = hipLaunchCooperativeKernel((const void *)k_sapx<CT, TXsel, NGsel>, dim3(KX), dim3(TXsel * NGsel), kargs, 0, c.stream);
             if (le == hipSuccess) launched_x = true;
             else (void)hipGetLastError();
         }
