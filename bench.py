@@ -393,7 +393,7 @@ def cpu_baseline(kind, n_gpu, seconds):
             "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "last_total": int(tot)}
 
 
-TRAFFIC_PROFILE = os.path.join("profiles", "r2", "rocprof_summary_r2i.json")   # the committed PMC summary the traffic figure is read from
+TRAFFIC_PROFILE = os.path.join("profiles", "r3", "rocprof_summary_r3_g1.json")   # the committed PMC summary the traffic figure is read from
 
 
 def pmc_traffic(kernel_class):
