@@ -47,11 +47,17 @@ class HipShard:
         # "use the library's own stream": sharing it would leave kernels and collectives unordered.)
         self.shared_stream = bool(share_torch_stream)
         self.stream = None
+        if self.shared_stream and HipShard._stream_owner is not None:
+            # td_set_stream is process-global: a second shard installing ITS stream would move the first one's
+            # kernels off the stream its collectives are ordered with
+            raise _ffi.TdError("another HipShard already shares its torch stream with the library: close it first, or pass "
+                               "share_torch_stream=False")
         if self.shared_stream:
             self.stream = torch.cuda.Stream()
             self.stream.wait_stream(torch.cuda.current_stream())   # inputs written on the caller's stream
             assert self.stream.cuda_stream != 0
             _ffi.check(self.lib.td_set_stream(ctypes.c_void_p(self.stream.cuda_stream)))
+            HipShard._stream_owner = self
         self.n, self.row0, self.nrows = n, row0, nrows
         self._cost = cost_rows  # keep alive: the library reads it again for the total
         h = ctypes.c_void_p()
@@ -78,7 +84,9 @@ class HipShard:
             self.h = None
         if self.stream is not None:
             self.stream.synchronize()
-            self.lib.td_set_stream(None)   # back to the library's own stream
+            if HipShard._stream_owner is self:
+                self.lib.td_set_stream(None)   # back to the library's own stream (the state a HipShard found)
+                HipShard._stream_owner = None
             self.stream = None
 
     # -- compression width agreement
@@ -110,6 +118,15 @@ class HipShard:
 
     # -- all rounds in one C call, the collective issued by the library itself (td_shard_rounds)
     _comm_key = None   # (world, rank) of the library's communicator in this process
+    _stream_owner = None   # the one HipShard whose torch stream is installed in the (process-global) library context
+
+    @classmethod
+    def destroy_comm(cls):
+        """td_comm_destroy + forget the cached communicator key (call before the process group goes away, or
+        before td.shutdown(): a later native_comm() builds a fresh communicator)."""
+        if cls._comm_key is not None:
+            _ffi.lib().td_comm_destroy()
+            cls._comm_key = None
 
     def native_comm(self, dist):
         """Builds (once per process) the library's own RCCL communicator: rank 0 makes the 128-byte

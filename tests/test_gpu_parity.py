@@ -57,6 +57,20 @@ def check_assignment(td, c):
     return r2c, total
 
 
+def test_julia_3x4_rectangular_on_gpu(td):
+    """julia.jl:3-15: 3 cabs x 4 requests, rows == 1, columns <= 1 -> optimum 1.  The reference's own way to a square
+    model is a dummy cab row (solver.py pads with one value): a constant row costs the same wherever it lands, so
+    total - that constant is the rectangular optimum.  Constant rows are deferred by td_assign (k_place_const)."""
+    c34 = np.array(GOLD["julia_3x4"]["cost"], np.int32)
+    for pad in (0, 16, 250000):
+        c = np.vstack([c34, np.full((1, 4), pad, np.int32)])
+        r2c, total, dual = td.assign(c, want_dual=True)
+        assert total - pad == GOLD["julia_3x4"]["total"] == 1 and dual == total
+        assert sorted(np.asarray(r2c).tolist()) == [0, 1, 2, 3]
+        assert int(c34[np.arange(3), np.asarray(r2c)[:3]].sum()) == 1
+        assert oracle.assign(c)[0] == total
+
+
 def test_known_answers(td):
     for key in ("pdf_table5", "procedure_py"):
         c = np.array(GOLD[key]["cost"], np.int32)

@@ -216,6 +216,53 @@ def test_lcm_sharded_through_rccl_one_rank(td):
     assert res == [True, True]
 
 
+def _rounds_worker(port, native, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["TD_SHARD_FORCE_AR"] = "1"          # issue ncclAllReduce with one rank too (read once per process)
+    os.environ["TD_SHARD_NATIVE"] = "1" if native else "0"
+    try:
+        import torch
+        import torch.distributed as dist
+        import taxidispatcher_amd as td
+        from oracle import oracle
+        from taxidispatcher_amd import sharded
+        td.init(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        n = 3000
+        cost = torch.from_numpy(oracle.gen_uniform(n, 5, 10, 40)).cuda()
+        sh = sharded.HipShard(n, 0, n, cost)
+        try:
+            r2c, total, dual = sharded.solve_sharded(sh, dist, want_dual=True)
+        finally:
+            sh.close()
+        sharded.HipShard.destroy_comm()
+        dist.destroy_process_group()
+        q.put(("ok", (np.asarray(r2c).tolist(), int(total), int(dual))))
+    except Exception as e:   # noqa: BLE001
+        q.put(("error", repr(e)))
+
+
+@pytest.mark.gpu
+def test_native_rccl_rounds_equal_python_rounds(td):
+    """td_shard_rounds calls ncclAllReduce through dlsym with hand-copied enum values (uint64, max).  With
+    TD_SHARD_FORCE_AR=1 the collective is issued with one rank too: the native loop (bid -> ncclAllReduce -> apply on the
+    library's stream) must give the same row_to_col and total as the Python loop over torch.distributed."""
+    ctx = mp.get_context("spawn")
+    res = []
+    for native in (True, False):
+        q = ctx.Queue()
+        p = ctx.Process(target=_rounds_worker, args=(_free_port(), native, q))
+        p.start()
+        status, out = q.get(timeout=300)
+        p.join(timeout=60)
+        assert status == "ok", out
+        res.append(out)
+    assert res[0][1] == res[1][1] == 10 * 3000 == res[0][2] == res[1][2]
+    assert res[0][0] == res[1][0], "native RCCL rounds and the Python rounds must be bit-identical"
+
+
 @pytest.mark.gpu
 def test_bench_sharded_leg_through_rccl(td):
     """The multi-GPU leg of bench.py with one rank: process group on the nccl backend, the library's
