@@ -3101,7 +3101,9 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
         };
         int nfree = 0, launched = 0;
         if ((rc = read_nfree(&nfree))) return rc;
-        while (nfree >= g_psap_min && launched < g_psap_cap) {
+        // a tick-sized model with a dozen free rows: the serial workgroup is through before a batch + its commit are (tick: 0.346 -> 0.332 ms)
+        const int psap_min = n < 2048 ? std::max(g_psap_min, 32) : g_psap_min;
+        while (nfree >= psap_min && launched < g_psap_cap) {
             const int nb = std::max(1, std::min(g_psap_batches, (nfree + 31) / 32));
             for (int b = 0; b < nb; b++) {
                 search();
@@ -3417,6 +3419,22 @@ int sv_readback(Solver &sv, int64_t *total, int64_t *dual, int max_rounds, int *
 
 }  // namespace
 
+// td_tick knows the model it hands over (how many dummy requests / cabs pad it, the fill value): the next td_assign call
+// skips the line probe and the speculative 1-byte attempt and goes straight to the fused pass when the shape rule says so
+namespace {
+struct AssignHint {
+    bool valid = false;
+    int const_cols = 0, const_rows = 0, fill = 0;
+} g_hint;
+}  // namespace
+void td::assign_hint_padded(int const_cols, int const_rows, int32_t fill)
+{
+    g_hint.valid = true;
+    g_hint.const_cols = const_cols;
+    g_hint.const_rows = const_rows;
+    g_hint.fill = fill;
+}
+
 // =====================================================================================
 // td_assign
 // =====================================================================================
@@ -3461,7 +3479,12 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     bool line_pending = false, early_check = false, r2c_in_pinned = false;
     constexpr size_t R2C_PIN_OFF = 8192;   // clear of the control words (0..), the totals (1024) and the probe verdict (4096)
     c.stats[8] = c.stats[9] = 0;
-    if (g_line && n >= g_line_min_n && !g_solver_eps) {
+    const AssignHint hint = g_hint;
+    g_hint.valid = false;
+    const int hint_margin = n / 256 > 32 ? n / 256 : 32;
+    const bool hinted_fuse = hint.valid && g_fuse_t && g_shape && !g_solver_eps && n >= 64 && hint.const_cols >= 16 &&
+                             hint.const_cols - hint.const_rows >= hint_margin && hint.fill >= 255 && (int64_t)hint.fill <= NP_RANGE;
+    if (!hinted_fuse && g_line && n >= g_line_min_n && !g_solver_eps) {
         if ((rc = line_probe_launch(n, sv.d_cost, &sv.skip))) return rc;
         line_pending = true;
     }
@@ -3470,10 +3493,25 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     bool solved = false, transposed = false, np_failed = false, no_fuse = false, fused_spec = false;
     int64_t range_hint = -1;
     sv.defer_const = g_defer_const && !g_solver_eps;
+    int64_t hinted_range = -1;
+    if (hinted_fuse) {   // the caller (td_tick) told the shape: the fused pass at once, speculatively (flags with the final read-back)
+        bool ff = false;
+        int64_t fr = 0;
+        fused_spec = true;
+        if (g_fuse_t >= 2 && n > 2048 && n <= 65536) {
+            if ((rc = sv_compress_fused(sv, &ff, &fr, true, hint.fill, true))) return rc;
+            sv.fused8 = ff;
+        }
+        if (!ff && (rc = sv_compress_fused(sv, &ff, &fr, false, 0, true))) return rc;
+        sv.fused_t = true;
+        transposed = true;
+        hinted_range = hint.fill;
+        max_rounds = std::min(max_rounds, g_fused_rounds);
+    }
 restart:
     for (int orient = 0; orient < 2 && !solved; orient++) {
     bool want_transpose = false;
-    int64_t known_range = transposed ? range_hint : -1;
+    int64_t known_range = sv.fused_t ? hinted_range : (transposed ? range_hint : -1);
     for (int bpc : {1, 2, 6, 5, 4}) {   // 5 = 4-byte cells with 32-bit prices (narrow-price mode, see u32n); 6 = 1-byte cells + escape (u8e, fused pass only)
         bool fits = false;
         if (bpc == 6 && !sv.fused8) continue;

@@ -66,6 +66,9 @@ int line_probe_wait(int *mode, int *k, int *suspicious = nullptr /* the 1-byte a
                     int *shape3 = nullptr /* int[4]: estimated constant columns / rows, row 0 too wide for one byte, value of the last column */);
 int line_finish(int n, int k, const int32_t *d_cost, const int32_t **r2c_dev, int64_t *total, int *accepted);
 void line_release_workspace();
+// td_assign.hip: a hint for the NEXT td_assign call of this process (consumed by it): the matrix is a model padded with
+// `const_cols` dummy requests and `const_rows` dummy cabs of value `fill` (td_tick knows this from its position arrays)
+void assign_hint_padded(int const_cols, int const_rows, int32_t fill);
 // td_lcm.hip: td_lcm with the candidate cells' value range given by the caller (no min / max pass, no host round trip);
 // a wrong hint is detected on the device and the call is redone with the measured range
 int lcm_hinted(int n, const int32_t *cost, int32_t mask, int32_t threshold, int stop_value_on, int32_t stop_value, int stop_size,

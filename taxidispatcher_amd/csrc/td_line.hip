@@ -37,7 +37,7 @@ namespace {
 // LC_PLAUS: 0 refused; 1 balanced line metric plausible; 2 constant trailing COLUMNS (retry on the transpose);
 //           3 plausible with LC_K constant rows (the unbalanced model: fewer cabs than requests)
 enum { LC_P = 0, LC_Q, LC_I1, LC_I2, LC_PLAUS, LC_REV, LC_FAIL, LC_FITS32, LC_TOTAL, LC_K, LC_FILL, LC_SKIP, LC_WORDS };
-constexpr int LINE_KMAX = 32;   // most constant rows the unbalanced plan is made for
+constexpr int LINE_KMAX = 256;  // most constant rows the unbalanced plan is made for: k prefix-min scans of n by one workgroup and O(k n) scratch (k = 256, n = 16 384: ~4 ms and 100 MB against > 400 ms for the general solver; 32 until round 3)
 
 struct LineWs {
     Buf ctl, kin, kout, vin, vout, tmp, f, v64, v32, r2c;

@@ -196,6 +196,7 @@ extern "C" int td_tick(const int32_t *cab_to, int n_s, const int32_t *dem_from, 
         if ((rc = ensure(t.cost_b, sizeof(int32_t) * (size_t)n2 * n2))) return rc;
         int32_t *d_b = (int32_t *)t.cost_b.p;
         if ((rc = td_cost_build(d_cab2, nullptr, kc, d_dem2, nullptr, kd, d_dist, S, fill, threshold, 0, d_b))) return rc;
+        td::assign_hint_padded(n2 - kd, n2 - kc, fill);   // dummy requests / dummy cabs of the remainder: no probe, no 1-byte attempt
         if ((rc = td_assign(n2, d_b, row_to_col, total, nullptr))) return rc;   // ends with a stream synchronisation
     } else {
         TD_HIP(hipStreamSynchronize(c.stream));

@@ -150,12 +150,12 @@ def padded_line_cost(rng, n_cabs, n_req, S, big=250000):
 
 @pytest.mark.parametrize("side", ["fewer_cabs", "fewer_requests"])
 def test_unbalanced_line_models(line_on, side):
-    """k = 1..32 missing cabs (constant rows) or requests (constant columns, solved on the transpose): the
-    certified plan must give the oracle's total; k = 33 is past LINE_KMAX and goes to the general solver"""
+    """k = 1..256 missing cabs (constant rows) or requests (constant columns, solved on the transpose): the
+    certified plan must give the oracle's total; k = 257 is past LINE_KMAX (32 until round 3) and goes to the general solver"""
     td = line_on
     rng = np.random.default_rng(21 if side == "fewer_cabs" else 22)
     for n in (5, 12, 40, 130, 400, 515):
-        for k in (1, 2, 3, 8, 17, 32, 33):
+        for k in (1, 2, 3, 8, 17, 32, 33, 100, 256, 257):
             if n - k < 2:
                 continue
             for S in (4, 60, 10 * n):
@@ -165,10 +165,10 @@ def test_unbalanced_line_models(line_on, side):
                 assert int(c[np.arange(n), r2c].astype(np.int64).sum()) == total == dual
                 assert total == oracle.assign(c)[0], (side, n, k, S)
                 st = td.last_stats()
-                if k <= 32 and S == 10 * n:
+                if k <= 256 and S == 10 * n:
                     assert st["line_metric"] == 1 and st["line_dummies"] == k, (side, n, k, S, st)
                     assert st["transposed"] == (1 if side == "fewer_requests" else 0)
-                if k == 33:
+                if k == 257:
                     assert st["line_metric"] == 0
 
 
