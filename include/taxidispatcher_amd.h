@@ -258,6 +258,20 @@ TD_API int td_shard_owner(td_shard *s, int32_t *owner, int set);
 TD_API int td_shard_price(td_shard *s, int64_t *price /* n, device */, int set);
 TD_API int td_shard_total(td_shard *s, int64_t *partial_total, int64_t *partial_dual);
 TD_API int td_shard_row_to_col(td_shard *s, int32_t *r2c_local);
+/* The sorted matching of td_assign's line-metric path (cost = |a_i - b_j|, perf.jl's G2 family) over ROW SHARDS.
+ * Replaces the same call as td_assign (simulator.py:199 / munkres.c solve / greedy_opt.py:95), for matrices one
+ * GPU cannot hold.  `ws` is td_line_shard_ws_words(n) 64-bit words of device memory owned by the caller.  Every
+ * rank runs phases 0, 1, 2, 3 in order and after EACH phase SUM-all-reduces ws[*seg_off .. *seg_off + *seg_len)
+ * with the other ranks (the segments are written disjointly and zero elsewhere, so the sum is the exchange; with
+ * one rank there is nothing to do).  phase 0: anchors from the rank that owns row 0; 1: row keys; 2: replicated
+ * sort, local matched cells and neighbours; 3: replicated prices, certificate pass over the local rows.
+ * td_line_shard_result (after phase 3's exchange): *accepted = 1 when every rank's rows certify the matching
+ * (then it is optimal, whatever the matrix was), *total its cost, row_to_col[0..nrows) (host or device) the
+ * columns of the local rows.  *accepted = 0: use the general sharded solve (td_shard_*). */
+TD_API int64_t td_line_shard_ws_words(int n);
+TD_API int td_line_shard_phase(int phase, int n, int row0, int nrows, const int32_t *cost_rows, int64_t *ws, int64_t *seg_off,
+                               int64_t *seg_len);
+TD_API int td_line_shard_result(int n, int row0, int nrows, const int64_t *ws, int32_t *row_to_col, int64_t *total, int32_t *accepted);
 TD_API int td_ipc_export(const void *dev_ptr, void *handle64);
 TD_API int td_ipc_open(const void *handle64, void **dev_ptr);
 TD_API int td_ipc_close(void *dev_ptr);

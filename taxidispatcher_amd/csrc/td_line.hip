@@ -620,12 +620,13 @@ __global__ __launch_bounds__(1024) void k_line_unbal(int n, int k, const int32_t
 
 // The certificate: row i passes when no cell of the row beats its matched cell, min_j (c[i][j] - v[j]) == c[i][m] - v[m].
 // R rows per workgroup sweep so a price vector chunk is loaded once per R cost chunks; 16-byte loads.
+// (nrows rows of n cells: the whole matrix, or one rank's row shard with r2c pointing at its first row's entry)
 template <typename VT, int R, bool VEC>
-__device__ void line_cert_body(int n, const int32_t *__restrict__ c, const VT *__restrict__ v, const int *__restrict__ r2c,
+__device__ void line_cert_body(int n, int nrows, const int32_t *__restrict__ c, const VT *__restrict__ v, const int *__restrict__ r2c,
                                long long *__restrict__ ctl, long long *sh)
 {
     const int t = threadIdx.x, T = blockDim.x, lane = t & 63, w = t >> 6, nw = T >> 6;
-    const int ngroups = (n + R - 1) / R;
+    const int ngroups = (nrows + R - 1) / R;
     for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const int r0 = g * R;
         long long m[R];
@@ -646,7 +647,7 @@ __device__ void line_cert_body(int n, const int32_t *__restrict__ c, const VT *_
                 v4i cv[R];
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const int row = std::min(r0 + r, n - 1);
+                    const int row = std::min(r0 + r, nrows - 1);
                     cv[r] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(c + (size_t)row * n) + ch);
                 }
 #pragma unroll
@@ -664,7 +665,7 @@ __device__ void line_cert_body(int n, const int32_t *__restrict__ c, const VT *_
                 const long long pv = (long long)v[j];
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const int row = std::min(r0 + r, n - 1);
+                    const int row = std::min(r0 + r, nrows - 1);
                     const long long a = (long long)c[(size_t)row * n + j] - pv;
                     m[r] = a < m[r] ? a : m[r];
                 }
@@ -682,7 +683,7 @@ __device__ void line_cert_body(int n, const int32_t *__restrict__ c, const VT *_
         if (lane == 0)
             for (int r = 0; r < R; r++) sh[r * 16 + w] = m[r];
         __syncthreads();
-        if (t < R && r0 + t < n) {
+        if (t < R && r0 + t < nrows) {
             long long mm = sh[t * 16];
             for (int k = 1; k < nw; k++) mm = sh[t * 16 + k] < mm ? sh[t * 16 + k] : mm;
             const int row = r0 + t, col = r2c[row];
@@ -693,17 +694,156 @@ __device__ void line_cert_body(int n, const int32_t *__restrict__ c, const VT *_
 }
 
 template <int R, bool VEC>
-__global__ __launch_bounds__(256) void k_line_cert(int n, const int32_t *__restrict__ c, const long long *__restrict__ v64,
+__global__ __launch_bounds__(256) void k_line_cert(int n, int nrows, const int32_t *__restrict__ c, const long long *__restrict__ v64,
                                                    const int32_t *__restrict__ v32, const int *__restrict__ r2c,
                                                    long long *__restrict__ ctl)
 {
     __shared__ long long sh[R * 16];
     if (ctl[LC_FAIL]) return;   // the gather pass already found a violation
     if (ctl[LC_FITS32])
-        line_cert_body<int32_t, R, VEC>(n, c, v32, r2c, ctl, sh);
+        line_cert_body<int32_t, R, VEC>(n, nrows, c, v32, r2c, ctl, sh);
     else
-        line_cert_body<long long, R, VEC>(n, c, v64, r2c, ctl, sh);
+        line_cert_body<long long, R, VEC>(n, nrows, c, v64, r2c, ctl, sh);
 }
+
+// -------------------------------------------------------------------------------------
+// The same plan over ROW SHARDS (one rank = rows [row0, row0 + nrows) x all n columns): everything O(n) is
+// replicated, the two O(rows) reads of the matrix (keys, differences) and the O(n^2 / world) certificate pass are
+// local, and the ranks meet in four SUM all-reduces of disjointly written, otherwise zero segments of one
+// workspace (so a sum IS the gather / broadcast, whatever the backend).  Workspace layout, 64-bit words,
+// N2 = n rounded up to 8:
+//   [0, 16)            ctl, indexed like the single-GPU path (LC_*)            | segment 0: written by the rank that
+//   [16, 16 + N2)      rows i1 = 0 and i2 of the matrix as int32 (2 * N2)      | owns row 0
+//   RK  n words        row keys, each rank its own rows                           segment 1
+//   FB  2 N2 + 1       f[k], b[k] by sorted position, + the matching's total      segment 2
+//   FAIL 1 word        certificate verdicts                                       segment 3
+//   then the replicated working set: sorted (2 N2 int), inv, r2c (N2 int each), v64, v32, the 2n sort pairs
+// -------------------------------------------------------------------------------------
+struct LshLayout {
+    size_t N2, ctl, anch, rk, fb, tot, failw, sorted, inv, r2c, v64, v32, kin, kout, vin, end;
+    explicit LshLayout(int n)
+    {
+        N2 = ((size_t)n + 7) & ~(size_t)7;
+        ctl = 0, anch = 16, rk = anch + N2, fb = rk + N2, tot = fb + 2 * N2, failw = tot + 1;
+        sorted = (failw + 1 + 7) & ~(size_t)7;
+        inv = sorted + N2, r2c = inv + N2 / 2, v64 = r2c + N2 / 2, v32 = v64 + N2, kin = v32 + N2 / 2, kout = kin + 2 * N2;
+        vin = kout + 2 * N2, end = vin + N2;
+    }
+};
+
+// the rank that owns row 0: anchors without a plausibility test (a wrong guess costs a refused certificate):
+// p = 0, q = the column whose distance to row 0 differs most from column 0's, i1 = 0, i2 = the local row that
+// differs most from row 0 in columns p and q
+__global__ __launch_bounds__(1024) void k_lsh_anchor(int n, int nrows, const int32_t *__restrict__ c, long long *__restrict__ ctl,
+                                                     int32_t *__restrict__ anch, size_t N2)
+{
+    __shared__ ArgMax sh[16];
+    const int t = threadIdx.x, T = blockDim.x;
+    const long long c00 = c[0];
+    ArgMax best = {-1, 0};
+    for (int j = t; j < n; j += T) {
+        const ArgMax x = {labs64((long long)c[j] - c00), j};
+        if (better(x, best)) best = x;
+    }
+    best = block_argmax(best, sh);
+    const int q = best.i;
+    const bool okq = best.v > 0;
+    const long long c0q = c[q];
+    ArgMax b2 = {-1, 0};
+    for (int i = t; i < nrows; i += T) {
+        const ArgMax x = {labs64((long long)c[(size_t)i * n] - c00) + labs64((long long)c[(size_t)i * n + q] - c0q), i};
+        if (better(x, b2)) b2 = x;
+    }
+    b2 = block_argmax(b2, sh);
+    const int i2 = b2.i;
+    const bool ok = okq && b2.v > 0;
+    for (int j = t; j < n; j += T) {
+        anch[j] = c[j];
+        anch[N2 + j] = c[(size_t)i2 * n + j];
+    }
+    if (t == 0) {
+        const long long a1 = c00, b1 = c0q, a2 = c[(size_t)i2 * n], b2v = c[(size_t)i2 * n + q];
+        ctl[LC_P] = 0;
+        ctl[LC_Q] = q;
+        ctl[LC_I1] = 0;
+        ctl[LC_I2] = i2;
+        ctl[LC_PLAUS] = ok;
+        ctl[LC_REV] = (a2 * a2 - b2v * b2v) < (a1 * a1 - b1 * b1);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lsh_rowkeys(int n, int row0, int nrows, const int32_t *__restrict__ c,
+                                                     const long long *__restrict__ ctl, long long *__restrict__ rk)
+{
+    const int q = (int)ctl[LC_Q];
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nrows; t += gridDim.x * blockDim.x) {
+        const long long x = c[(size_t)t * n], y = c[(size_t)t * n + q];
+        rk[row0 + t] = x * x - y * y + (1ll << 62);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lsh_keys(int n, const long long *__restrict__ ctl, const int32_t *__restrict__ anch, size_t N2,
+                                                  const long long *__restrict__ rk, unsigned long long *__restrict__ keys,
+                                                  int *__restrict__ vals)
+{
+    const bool rev = ctl[LC_REV] != 0;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < 2 * n; t += gridDim.x * blockDim.x) {
+        if (t < n) {
+            keys[t] = (unsigned long long)rk[t];
+            vals[t] = t;
+        } else {
+            const long long x = anch[t - n], y = anch[N2 + t - n];
+            long long key = x * x - y * y;
+            if (rev) key = -key;
+            keys[t] = (unsigned long long)(key + (1ll << 62)) | 1ull << 63;
+            vals[t] = t - n;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lsh_inv(int n, const int *__restrict__ sorted, int *__restrict__ inv, int *__restrict__ r2c)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        inv[sorted[k]] = k;
+        r2c[sorted[k]] = sorted[n + k];
+    }
+}
+
+// each local row's matched cell and its two neighbours along the sorted columns: f[k] and b[k - 1] of k_line_gather
+__global__ __launch_bounds__(256) void k_lsh_diffs(int n, int row0, int nrows, const int32_t *__restrict__ c, const int *__restrict__ sorted,
+                                                   const int *__restrict__ inv, long long *__restrict__ F, long long *__restrict__ B,
+                                                   long long *__restrict__ tot)
+{
+    __shared__ long long sh[4];
+    const int *tau = sorted + n;
+    long long sum = 0;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nrows; t += gridDim.x * blockDim.x) {
+        const int k = inv[row0 + t];
+        const int32_t *row = c + (size_t)t * n;
+        const long long ckk = row[tau[k]];
+        if (k + 1 < n) F[k] = (long long)row[tau[k + 1]] - ckk;
+        if (k > 0) B[k - 1] = (long long)row[tau[k - 1]] - ckk;
+        sum += ckk;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sum = sh[0] + sh[1] + sh[2] + sh[3];
+        if (sum) atomicAdd((unsigned long long *)tot, (unsigned long long)sum);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lsh_monge(int n, const long long *__restrict__ F, const long long *__restrict__ B,
+                                                   long long *__restrict__ ctl)
+{
+    int bad = ctl[LC_PLAUS] == 0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k + 1 < n; k += gridDim.x * blockDim.x) bad |= F[k] + B[k] < 0;
+    if (bad) ctl[LC_FAIL] = 1;
+}
+
+__global__ void k_lsh_publish(const long long *__restrict__ ctl, long long *__restrict__ failw) { *failw = ctl[LC_FAIL] != 0; }
 
 }  // namespace
 
@@ -800,10 +940,10 @@ int line_finish(int n, int k, const int32_t *d_cost, const int32_t **r2c_dev, in
         const int grid = std::max(1, std::min(ngroups, c.n_cu * 16));
         const bool vec = (n % 4 == 0) && (((uintptr_t)d_cost & 15) == 0);
         if (vec)
-            k_line_cert<R, true><<<grid, 256, 0, c.stream>>>(n, d_cost, (const long long *)g_lw.v64.p, (const int32_t *)g_lw.v32.p,
+            k_line_cert<R, true><<<grid, 256, 0, c.stream>>>(n, n, d_cost, (const long long *)g_lw.v64.p, (const int32_t *)g_lw.v32.p,
                                                              (const int *)g_lw.r2c.p, ctl);
         else
-            k_line_cert<R, false><<<grid, 256, 0, c.stream>>>(n, d_cost, (const long long *)g_lw.v64.p, (const int32_t *)g_lw.v32.p,
+            k_line_cert<R, false><<<grid, 256, 0, c.stream>>>(n, n, d_cost, (const long long *)g_lw.v64.p, (const int32_t *)g_lw.v32.p,
                                                               (const int *)g_lw.r2c.p, ctl);
         TD_HIP(hipGetLastError());
     }
@@ -832,3 +972,93 @@ void line_release_workspace()
 }
 
 }  // namespace td
+
+using namespace td;
+
+// ---- C ABI: the sorted matching over row shards (see the layout above k_lsh_anchor) ----
+extern "C" int64_t td_line_shard_ws_words(int n) { return n < 2 ? 0 : (int64_t)LshLayout(n).end; }
+
+extern "C" int td_line_shard_phase(int phase, int n, int row0, int nrows, const int32_t *cost_rows, int64_t *ws, int64_t *seg_off,
+                                   int64_t *seg_len)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (n < 2 || row0 < 0 || nrows < 0 || (long long)row0 + nrows > n) return fail(TD_EINVAL, "td_line_shard_phase: bad shard %d+%d of %d", row0, nrows, n);
+    if (!ws || !seg_off || !seg_len) return fail(TD_EINVAL, "td_line_shard_phase: null argument");
+    if (nrows > 0 && (!cost_rows || !is_device_ptr(cost_rows))) return fail(TD_EINVAL, "td_line_shard_phase: cost_rows must be device memory");
+    if (!is_device_ptr(ws)) return fail(TD_EINVAL, "td_line_shard_phase: ws must be device memory");
+    const LshLayout L(n);
+    long long *w = (long long *)ws, *ctl = w + L.ctl;
+    const int grid_rows = std::max(1, std::min(c.n_cu * 4, (nrows + 255) / 256));
+    const int grid_n = std::max(1, std::min(c.n_cu * 4, (2 * n + 255) / 256));
+    int rc;
+    ProfScope ps(phase == 3 ? TD_K_CERT : TD_K_LINE);
+    switch (phase) {
+    case 0:   // anchors, from the rank that owns row 0
+        TD_HIP(hipMemsetAsync(w, 0, L.end * 8, c.stream));
+        if (row0 == 0 && nrows > 0) k_lsh_anchor<<<1, 1024, 0, c.stream>>>(n, nrows, cost_rows, ctl, (int32_t *)(w + L.anch), L.N2);
+        *seg_off = 0, *seg_len = (int64_t)(L.anch + L.N2);
+        break;
+    case 1:   // row keys of the local rows
+        if (nrows > 0) k_lsh_rowkeys<<<grid_rows, 256, 0, c.stream>>>(n, row0, nrows, cost_rows, ctl, w + L.rk);
+        *seg_off = (int64_t)L.rk, *seg_len = n;
+        break;
+    case 2: {   // replicated: the sort; local: matched cells and their neighbours
+        auto *kin = (unsigned long long *)(w + L.kin), *kout = (unsigned long long *)(w + L.kout);
+        int *vin = (int *)(w + L.vin), *sorted = (int *)(w + L.sorted);
+        k_lsh_keys<<<grid_n, 256, 0, c.stream>>>(n, ctl, (const int32_t *)(w + L.anch), L.N2, w + L.rk, kin, vin);
+        size_t bytes = 0;
+        TD_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin, kout, vin, sorted, 2 * n, 0, 64, c.stream));
+        if ((rc = ensure(g_lw.tmp, bytes + 256))) return rc;
+        TD_HIP(hipcub::DeviceRadixSort::SortPairs(g_lw.tmp.p, bytes, kin, kout, vin, sorted, 2 * n, 0, 64, c.stream));
+        k_lsh_inv<<<grid_n, 256, 0, c.stream>>>(n, sorted, (int *)(w + L.inv), (int *)(w + L.r2c));
+        if (nrows > 0)
+            k_lsh_diffs<<<grid_rows, 256, 0, c.stream>>>(n, row0, nrows, cost_rows, sorted, (const int *)(w + L.inv), w + L.fb, w + L.fb + L.N2,
+                                                         w + L.tot);
+        *seg_off = (int64_t)L.fb, *seg_len = (int64_t)(2 * L.N2 + 1);
+        break;
+    }
+    case 3: {   // replicated: Monge test and prices; local: the certificate pass over this rank's rows
+        k_lsh_monge<<<grid_n, 256, 0, c.stream>>>(n, w + L.fb, w + L.fb + L.N2, ctl);
+        k_line_scan<<<1, 1024, 0, c.stream>>>(n, (const int *)(w + L.sorted), ctl, w + L.fb, w + L.v64, (int32_t *)(w + L.v32));
+        if (nrows > 0) {
+            constexpr int R = 4;
+            const int grid = std::max(1, std::min((nrows + R - 1) / R, c.n_cu * 16));
+            const bool vec = (n % 4 == 0) && (((uintptr_t)cost_rows & 15) == 0);
+            const int *r2c = (const int *)(w + L.r2c) + row0;
+            if (vec)
+                k_line_cert<R, true><<<grid, 256, 0, c.stream>>>(n, nrows, cost_rows, w + L.v64, (const int32_t *)(w + L.v32), r2c, ctl);
+            else
+                k_line_cert<R, false><<<grid, 256, 0, c.stream>>>(n, nrows, cost_rows, w + L.v64, (const int32_t *)(w + L.v32), r2c, ctl);
+        }
+        k_lsh_publish<<<1, 1, 0, c.stream>>>(ctl, w + L.failw);
+        *seg_off = (int64_t)L.failw, *seg_len = 1;
+        break;
+    }
+    default:
+        return fail(TD_EINVAL, "td_line_shard_phase: phase %d (0..3)", phase);
+    }
+    TD_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+extern "C" int td_line_shard_result(int n, int row0, int nrows, const int64_t *ws, int32_t *row_to_col, int64_t *total, int32_t *accepted)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (n < 2 || !ws || !total || !accepted || row0 < 0 || nrows < 0 || (long long)row0 + nrows > n)
+        return fail(TD_EINVAL, "td_line_shard_result: bad argument");
+    const LshLayout L(n);
+    long long h[2];
+    TD_HIP(hipMemcpyAsync(c.pinned, ws + L.tot, 16, hipMemcpyDeviceToHost, c.stream));   // total, summed verdicts
+    TD_HIP(hipStreamSynchronize(c.stream));
+    memcpy(h, c.pinned, 16);
+    *accepted = h[1] == 0;
+    *total = h[0];
+    if (*accepted && row_to_col && nrows > 0) {
+        TD_HIP(hipMemcpyAsync(row_to_col, (const int *)(ws + L.r2c) + row0, 4 * (size_t)nrows,
+                              is_device_ptr(row_to_col) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipStreamSynchronize(c.stream));
+    }
+    return TD_OK;
+}

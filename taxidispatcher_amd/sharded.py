@@ -239,6 +239,27 @@ class HipShard:
     def scalar_tensor(self, values, dtype=None):
         return self.torch.tensor(values, dtype=dtype or self.torch.int64, device=self.device)
 
+    # -- the sorted matching of line-metric matrices over row shards (td_line_shard_*)
+    def line_ws(self):
+        return self.torch.empty(int(self.lib.td_line_shard_ws_words(self.n)), dtype=self.torch.int64, device=self.device)
+
+    def line_phase(self, phase, ws):
+        """runs one phase on this shard's rows; returns the (offset, length) of ws to SUM over all shards"""
+        off, ln = ctypes.c_int64(0), ctypes.c_int64(0)
+        _ffi.check(self.lib.td_line_shard_phase(phase, self.n, self.row0, self.nrows, _ffi.addr(self._cost) if self.nrows else None,
+                                                ws.data_ptr(), ctypes.byref(off), ctypes.byref(ln)))
+        if not self.shared_stream:
+            _ffi.check(self.lib.td_synchronize())   # the exchange runs on torch's stream
+        return int(off.value), int(ln.value)
+
+    def line_result(self, ws):
+        """(accepted, total, local row_to_col) after the last exchange"""
+        r = np.empty(self.nrows, np.int32)
+        tot, acc = ctypes.c_int64(0), ctypes.c_int32(0)
+        _ffi.check(self.lib.td_line_shard_result(self.n, self.row0, self.nrows, ws.data_ptr(), r.ctypes.data if self.nrows else None,
+                                                 ctypes.byref(tot), ctypes.byref(acc)))
+        return bool(acc.value), int(tot.value), r
+
 
 def _staged(dist, t):
     """gloo has no device collectives on every build: stage device tensors through the host."""
@@ -291,6 +312,38 @@ def all_gather_equal(dist, t):
     return out
 
 
+LINE_PHASES = 4
+
+
+def line_sharded(shards, dist):
+    """The line-metric path of td_assign over row shards: `shards` = the shards THIS process drives (one
+    per rank in production; several in one process for single-GPU tests and timing), `dist` = torch.distributed or
+    None.  Four phases, each followed by ONE SUM all-reduce of a segment every shard writes disjointly (O(n) words;
+    the O(n^2 / world) certificate pass stays local).  Returns (total, [local row_to_col per shard]) when every
+    shard's rows certify the sorted matching - it is then optimal whatever the matrix was - else None (the caller
+    runs the general sharded solve)."""
+    world = dist.get_world_size() if dist is not None else 1
+    wss = [sh.line_ws() for sh in shards]
+    for phase in range(LINE_PHASES):
+        segs = []
+        for sh, ws in zip(shards, wss):
+            off, ln = sh.line_phase(phase, ws)
+            segs.append(ws[off:off + ln])
+        red = segs[0]
+        for sg in segs[1:]:
+            red += sg
+        if world > 1:
+            all_reduce(dist, red, dist.ReduceOp.SUM)
+        for sg in segs[1:]:
+            sg.copy_(red)
+        if len(segs) > 1:
+            _fence(red)
+    out = [sh.line_result(ws) for sh, ws in zip(shards, wss)]
+    if not all(acc for acc, _, _ in out):
+        return None
+    return out[0][1], [r for _, _, r in out]
+
+
 def solve_sharded(shard, dist, rounds=DEFAULT_ROUNDS, want_dual=False, use_ipc=None):
     """Collective part of the sharded solve; `shard` implements the HipShard interface and `dist`
     is torch.distributed (initialised). Returns (local row_to_col, total[, dual])."""
@@ -308,6 +361,15 @@ def _solve_sharded(shard, dist, rounds, want_dual, use_ipc):
     _, _, rps = shard_bounds(n, world, rank)
     MIN, MAX, SUM = dist.ReduceOp.MIN, dist.ReduceOp.MAX, dist.ReduceOp.SUM
     _NEED_FENCE = not getattr(shard, "shared_stream", False)
+    # 0. the sorted matching first (td_assign's order): O(n) exchanged, one local pass over the rows; accepted only
+    #    when every rank's rows certify it (total == dual bound by construction)
+    solve_sharded.last_path = "auction"
+    if hasattr(shard, "line_phase") and n >= 2 and os.environ.get("TD_LINE", "1") != "0":
+        got = line_sharded([shard], dist)
+        solve_sharded.last_path = "line" if got is not None else "auction"
+        if got is not None:
+            total, (r2c,) = got
+            return (r2c, total, total) if want_dual else (r2c, total)
     # 1. agree on the storage width (every rank must use the same one)
     for width in (1, 2, 4):
         flag = shard.scalar_tensor([1 if shard.compress(width) else 0])

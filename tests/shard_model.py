@@ -148,6 +148,70 @@ class ModelShard:
     def scalar_tensor(self, values, dtype=None):
         return torch.tensor(values, dtype=dtype or torch.int64)
 
+    # -- numpy model of td_line_shard_* (the sorted matching over row shards): same four phases and exchanged
+    #    segments as the device path; the replicated part (sort, prices) is recomputed from the summed segments
+    def line_ws(self):
+        n = self.n
+        return torch.zeros(16 + 2 * n + n + 2 * n + 2, dtype=torch.int64)
+
+    def line_phase(self, phase, ws):
+        n, c, w = self.n, self.cost, ws.numpy()
+        A, RK, FB = 16, 16 + 2 * n, 16 + 3 * n
+        TOT, FAIL = FB + 2 * n, FB + 2 * n + 1
+        if phase == 0:
+            w[:] = 0
+            if self.row0 == 0 and self.nrows > 0:
+                d = np.abs(c[0] - c[0, 0])
+                q = int(np.argmax(d))
+                e = np.abs(c[:, 0] - c[0, 0]) + np.abs(c[:, q] - c[0, q])
+                i2 = int(np.argmax(e))
+                k1 = c[0, 0] ** 2 - c[0, q] ** 2
+                k2 = c[i2, 0] ** 2 - c[i2, q] ** 2
+                w[0:4] = [q, i2, int(k2 < k1), int(d[q] > 0 and e[i2] > 0)]
+                w[A:A + n] = c[0]
+                w[A + n:A + 2 * n] = c[i2]
+            return 0, A + 2 * n
+        if phase == 1:
+            q = int(w[0])
+            if self.nrows:
+                w[RK + self.row0:RK + self.row0 + self.nrows] = c[:, 0] ** 2 - c[:, q] ** 2 + (1 << 62)
+            return RK, n
+        if phase == 2:
+            ck = w[A:A + n] ** 2 - w[A + n:A + 2 * n] ** 2
+            if w[2]:
+                ck = -ck
+            self.sig = np.argsort(w[RK:RK + n], kind="stable")
+            self.tau = np.argsort(ck, kind="stable")
+            inv = np.empty(n, np.int64)
+            inv[self.sig] = np.arange(n)
+            for t in range(self.nrows):
+                k = int(inv[self.row0 + t])
+                ckk = c[t, self.tau[k]]
+                if k + 1 < n:
+                    w[FB + k] = c[t, self.tau[k + 1]] - ckk
+                if k > 0:
+                    w[FB + n + k - 1] = c[t, self.tau[k - 1]] - ckk
+                w[TOT] += ckk
+            self.line_r2c = self.tau[inv[self.row0:self.row0 + self.nrows]]
+            return FB, 2 * n + 1
+        if phase == 3:
+            F, B = w[FB:FB + n], w[FB + n:FB + 2 * n]
+            bad = (w[3] == 0) or bool((F[:n - 1] + B[:n - 1] < 0).any())
+            v = np.zeros(n, np.int64)
+            v[self.tau] = np.concatenate(([0], np.cumsum(F[:n - 1])))
+            if not bad and self.nrows:
+                red = c - v[None, :]
+                tight = red[np.arange(self.nrows), self.line_r2c]
+                bad = bool((red.min(1) != tight).any())
+            w[FAIL] = int(bad)
+            return FAIL, 1
+        raise ValueError(phase)
+
+    def line_result(self, ws):
+        n = self.n
+        w = ws.numpy()
+        return bool(w[16 + 5 * n + 1] == 0), int(w[16 + 5 * n]), self.line_r2c.astype(np.int32)
+
     def close(self):
         pass
 

@@ -285,3 +285,115 @@ def test_bench_sharded_leg_through_rccl(td):
     sh = line["sharded_single_instance"]
     assert "error" not in sh, sh
     assert sh["optimal"] and sh["total_cost"] == 10 * 8192 and sh["speedup_vs_single_gpu"] > 0
+
+
+def _line_instance(n, seed, spread=10):
+    rng = np.random.default_rng(seed)
+    a, b = rng.integers(0, spread * n, n), rng.integers(0, spread * n, n)
+    return np.abs(a[:, None] - b[None, :]).astype(np.int32), a, b
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,world,spread", [(2048, 4, 10), (1001, 3, 10), (513, 8, 1), (4096, 1, 1000), (96, 5, 10)])
+def test_line_sharded_in_process_equals_sorted_matching(td, n, world, spread):
+    """the line-metric path over row shards (td_line_shard_*), `world` shards driven in one process:
+    the total is the sorted matching's (== the oracle's optimum), every shard certifies its rows, the local
+    row_to_col pieces form a permutation; ragged shards, n % 4 != 0 (scalar certificate loads), duplicate positions."""
+    import torch
+    from oracle import oracle
+    from taxidispatcher_amd import sharded
+    cost, a, b = _line_instance(n, 21, spread)
+    ref = int(np.abs(np.sort(a) - np.sort(b)).sum())     # an optimal matching of points on a line does not cross
+    if n <= 1001:
+        assert ref == oracle.assign(cost)[0]
+    full = torch.from_numpy(cost).cuda()
+    shards = []
+    try:
+        for r in range(world):
+            row0, nrows, _ = sharded.shard_bounds(n, world, r)
+            shards.append(sharded.HipShard(n, row0, nrows, full[row0:row0 + nrows], share_torch_stream=False))
+        got = sharded.line_sharded(shards, None)
+    finally:
+        for s in shards:
+            s.close()
+    assert got is not None
+    total, parts = got
+    r2c = np.concatenate(parts)
+    assert total == ref
+    assert sorted(r2c.tolist()) == list(range(n))
+    assert int(cost[np.arange(n), r2c].sum()) == ref
+
+
+@pytest.mark.gpu
+def test_line_sharded_refuses_other_matrices(td):
+    """a matrix that is no line metric (uniform, thresholded |a - b|, one perturbed cell) is refused by the shards'
+    certificates, never answered wrongly"""
+    import torch
+    from oracle import oracle
+    from taxidispatcher_amd import sharded
+    n, world = 1024, 4
+    cost, _, _ = _line_instance(n, 4)
+    thr = cost.copy()
+    thr[thr >= 900] = 250000
+    bumped = cost.copy()
+    bumped[n // 2 + 3, 5] = max(0, int(bumped[n // 2 + 3, 5]) - 400)    # one cheaper cell in another shard's row
+    for m in (oracle.gen_uniform(n, 3, 10, 40), thr, bumped):
+        full = torch.from_numpy(m).cuda()
+        shards = []
+        try:
+            for r in range(world):
+                row0, nrows, _ = sharded.shard_bounds(n, world, r)
+                shards.append(sharded.HipShard(n, row0, nrows, full[row0:row0 + nrows], share_torch_stream=False))
+            got = sharded.line_sharded(shards, None)
+        finally:
+            for s in shards:
+                s.close()
+        if got is not None:      # (a perturbation that leaves the sorted matching optimal may still certify)
+            assert got[0] == oracle.assign(m)[0]
+        else:
+            assert m is not cost
+
+
+def _line_rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        import torch
+        import torch.distributed as dist
+        import taxidispatcher_amd as td
+        from taxidispatcher_amd import sharded
+        td.init(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        n = 3000
+        cost, a, b = _line_instance(n, 8)
+        sh = sharded.HipShard(n, 0, n, torch.from_numpy(cost).cuda())
+        try:
+            r2c, total, dual = sharded.solve_sharded(sh, dist, want_dual=True)
+            path = sharded.solve_sharded.last_path
+            os.environ["TD_LINE"] = "0"
+            r2, t2, d2 = sharded.solve_sharded(sh, dist, want_dual=True)
+            path2 = sharded.solve_sharded.last_path if hasattr(sharded.solve_sharded, "last_path") else None
+        finally:
+            sh.close()
+        sharded.HipShard.destroy_comm()
+        dist.destroy_process_group()
+        ref = int(np.abs(np.sort(a) - np.sort(b)).sum())
+        ok = total == dual == t2 == d2 == ref and sorted(np.asarray(r2c).tolist()) == list(range(n))
+        q.put(("ok" if ok else "mismatch", (path, path2, int(total), int(t2), ref)))
+    except Exception as e:   # noqa: BLE001
+        q.put(("error", repr(e)))
+
+
+@pytest.mark.gpu
+def test_solve_sharded_takes_the_line_path_under_rccl(td):
+    """solve_sharded on the nccl backend (one rank): |a - b| rows go through the line phases on the shard's shared
+    stream (device segments all-reduced by RCCL's ordering), TD_LINE=0 forces the auction: same optimum"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_line_rccl_worker, args=(_free_port(), q))
+    p.start()
+    status, out = q.get(timeout=300)
+    p.join(timeout=60)
+    assert status == "ok", out
+    assert out[0] == "line"

@@ -104,6 +104,51 @@ def test_three_ranks_uneven_shards():
     assert sorted(r3.tolist()) == list(range(n))
 
 
+@pytest.mark.parametrize("world,kind,n,path", [(2, "g2", 61, "line"), (3, "g2", 50, "line"), (2, "g1", 40, "auction"),
+                                               (2, "g3", 64, "auction"), (3, "g2dup", 47, "line")])
+def test_sharded_line_path_over_ranks(world, kind, n, path):
+    """the sorted matching over row shards (four SUM all-reduces of O(n) words): taken for |a - b| matrices, refused
+    (and the auction run) for the others; duplicates in the positions do not matter"""
+    from oracle import oracle
+    if kind == "g2dup":
+        rng = np.random.default_rng(3)
+        a, b = rng.integers(0, 12, n), rng.integers(0, 12, n)
+        cost = np.abs(a[:, None] - b[None, :]).astype(np.int32)
+    else:
+        cost = _instance(kind, n, 11)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_line_worker_inst, args=(r, world, port, cost, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r2c = np.array([c for _, part, _, _, _ in outs for c in part])
+    ref = oracle.assign(cost)[0]
+    assert {t for _, _, t, _, _ in outs} == {ref} and {d for _, _, _, d, _ in outs} == {ref}
+    assert {pp for *_, pp in outs} == {path}
+    assert sorted(r2c.tolist()) == list(range(n))
+    assert int(cost[np.arange(n), r2c].sum()) == ref
+
+
+def _line_worker_inst(rank, world, port, cost, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from shard_model import ModelShard
+    from taxidispatcher_amd import sharded
+    n = cost.shape[0]
+    row0, nrows, rps = sharded.shard_bounds(n, world, rank)
+    sh = ModelShard(n, row0, nrows, cost[row0:row0 + nrows])
+    r2c, total, dual = sharded.solve_sharded(sh, dist, rounds=8, want_dual=True)
+    q.put((rank, r2c.tolist(), total, dual, sharded.solve_sharded.last_path))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _pool_worker(rank, world, port, name, k, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
