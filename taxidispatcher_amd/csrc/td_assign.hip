@@ -2670,6 +2670,32 @@ __global__ void k_r2c_from_owner(int n, int nrows, int row0, const int *__restri
     }
 }
 
+// constant-row deferral over row shards: each rank marks its constant rows in a replicated mask (summed by the
+// caller); the finisher's rank hides them from the searches (-2) and counts them for place_const_tail
+__global__ void k_const_mask(int row0, int nrows, const int *__restrict__ rconst, int *__restrict__ mask_full)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nrows && rconst[i]) mask_full[row0 + i] = 1;
+}
+
+__global__ __launch_bounds__(1024) void k_mark_const(int n, const int *__restrict__ mask, int *__restrict__ r2c_full, int *__restrict__ ctl)
+{
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        if (mask[i]) {
+            r2c_full[i] = -2;
+            cnt++;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) ctl[CTL_NCONST] = s_cnt;
+}
+
 // replicated prices <-> plain int64 (for the broadcast after the finisher changed them on one rank)
 template <typename PT>
 __global__ void k_price_io(int n, PT *pk, long long *plain, int set)
@@ -2748,12 +2774,14 @@ struct td_shard {
     int nconst = -1;                 // constant rows counted by the last compress pass (-1: not read back)
     const int32_t *probe = nullptr;  // non-null for the one k_init_state launch that carries the shape probe
     bool placed = false;       // ... and the finisher kernel has already placed them (no k_place_const launch)
+    Buf cmask;                 // sharded solve: the replicated mask of constant rows (td_shard_const_rows)
+    bool have_cmask = false;
     bool fused_t = false;      // cc holds the TRANSPOSED problem built straight from the caller's matrix (k_compress_tr): d_cost is not transposed
     bool fused8 = false;       // ... as 1-byte cells with the escape code (u8e, bpc code 6)
     const long long *skip = nullptr;  // device flag of a pending line-metric probe: non-zero makes the compress pass a no-op
     void free_all()
     {
-        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &rconst, &misc, &psrec, &tbuf, &xbuf, &fbuf};
+        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &rconst, &misc, &psrec, &tbuf, &xbuf, &fbuf, &cmask};
         for (Buf *b : bs) {
             if (b->p) (void)hipFree(b->p);
             b->p = nullptr;
@@ -3872,6 +3900,29 @@ int td_shard_compress(td_shard *s, int bytes_per_cell, int *fits)
     return rc;
 }
 
+// Constant rows (dummy cabs of a padded model) sit out the sharded solve as they do in td_assign: between
+// td_shard_compress and td_shard_begin every rank writes its constant rows into a zeroed mask of n ints (set = 0),
+// the caller SUM-all-reduces it and hands the result back (set = 1).  The rows then never bid, the finisher's rank
+// skips them and gives them the columns nobody owns at the end (k-th constant row <- k-th free column).
+int td_shard_const_rows(td_shard *s, int32_t *mask_full, int set)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (!s || !mask_full || !s->bpc) return fail(TD_EINVAL, "td_shard_const_rows: null argument or shard not compressed");
+    if (!is_device_ptr(mask_full)) return fail(TD_EINVAL, "td_shard_const_rows: the mask must be device memory");
+    if (!set) {
+        if (s->nrows > 0) k_const_mask<<<(s->nrows + 255) / 256, 256, 0, c.stream>>>(s->row0, s->nrows, (const int *)s->rconst.p, mask_full);
+        TD_HIP(hipGetLastError());
+        return TD_OK;
+    }
+    int rc;
+    if ((rc = ensure(s->cmask, sizeof(int) * (size_t)(s->n + 16)))) return rc;
+    TD_HIP(hipMemcpyAsync(s->cmask.p, mask_full, sizeof(int) * (size_t)s->n, hipMemcpyDeviceToDevice, c.stream));
+    s->have_cmask = true;
+    s->defer_const = g_defer_const && !g_solver_eps;
+    return TD_OK;
+}
+
 int td_shard_range(td_shard *s, int64_t *range)
 {
     TD_REQUIRE_INIT();
@@ -4049,8 +4100,13 @@ int td_shard_finish(td_shard *s, int world, const void *const *shard_ptrs, int r
     int *full = (int *)s->r2c_full.p;
     k_fill_i32<<<(n + 255) / 256, 256, 0, c.stream>>>(full, n, -1);
     k_r2c_from_owner<<<(n + 255) / 256, 256, 0, c.stream>>>(n, n, 0, (const int *)s->owner.p, full);
+    const bool deferred = s->defer_const && s->have_cmask;
+    if (deferred) k_mark_const<<<1, 1024, 0, c.stream>>>(n, (const int *)s->cmask.p, full, (int *)s->misc.p);
+    s->placed = false;
     TD_DISPATCH(*s, sv_finish_t, *s, tab, full);
     if (rc) return rc;
+    if (deferred && !s->placed)
+        k_place_const<<<1, 1024, 0, c.stream>>>(n, full, (int *)s->owner.p, (int *)s->list.p, (int *)s->pred.p, (int *)s->misc.p);
     // the finisher moved assignments: rebuild this rank's local row_to_col from owner[]
     if (s->nrows > 0) {
         k_fill_i32<<<(s->nrows + 255) / 256, 256, 0, c.stream>>>((int *)s->r2c.p, s->nrows, -1);

@@ -239,6 +239,22 @@ class HipShard:
     def scalar_tensor(self, values, dtype=None):
         return self.torch.tensor(values, dtype=dtype or self.torch.int64, device=self.device)
 
+    # -- constant rows sit out the solve (td_shard_const_rows)
+    def const_mask(self):
+        """zeroed device mask of n ints with this shard's constant rows set (after compress); the caller sums it"""
+        m = self.torch.zeros(self.n, dtype=self.torch.int32, device=self.device)
+        if not self.shared_stream:
+            self.torch.cuda.current_stream().synchronize()   # the fill runs on torch's stream, the kernel on the library's
+        _ffi.check(self.lib.td_shard_const_rows(self.h, m.data_ptr(), 0))
+        if not self.shared_stream:
+            _ffi.check(self.lib.td_synchronize())
+        return m
+
+    def set_const_mask(self, mask):
+        _ffi.check(self.lib.td_shard_const_rows(self.h, mask.data_ptr(), 1))
+        if not self.shared_stream:
+            _ffi.check(self.lib.td_synchronize())
+
     # -- the sorted matching of line-metric matrices over row shards (td_line_shard_*)
     def line_ws(self):
         return self.torch.empty(int(self.lib.td_line_shard_ws_words(self.n)), dtype=self.torch.int64, device=self.device)
@@ -379,6 +395,13 @@ def _solve_sharded(shard, dist, rounds, want_dual, use_ipc):
             break
     else:
         raise _ffi.TdError("row cost range exceeds 2^32-2 on some rank")
+    # constant rows (dummy cabs of a padded model) sit out the rounds and the searches, as in td_assign: one SUM
+    # all-reduce of an n-int mask tells every rank (the finisher's above all) which rows they are
+    if hasattr(shard, "const_mask") and os.environ.get("TD_DEFER_CONST", "1") != "0":
+        mask = shard.const_mask()
+        if world > 1:
+            all_reduce(dist, mask, SUM)
+        shard.set_const_mask(mask)
     # the packed-key range guard needs the largest row range of ANY rank (td_assign's TD_ERANGE rule)
     grange = -1
     if hasattr(shard, "range"):

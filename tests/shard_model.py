@@ -36,6 +36,18 @@ class ModelShard:
         self.p = np.zeros(self.n, np.int64)
         self.owner = np.full(self.n, -1, np.int64)
         self.r2c = np.full(self.nrows, -1, np.int64)
+        if getattr(self, "cmask", None) is not None:
+            self.r2c[self.cmask[self.row0:self.row0 + self.nrows]] = -2   # deferred: never bid, never searched
+
+    # constant rows sit out the solve (model of td_shard_const_rows)
+    def const_mask(self):
+        m = torch.zeros(self.n, dtype=torch.int32)
+        if self.nrows:
+            m[self.row0:self.row0 + self.nrows] = torch.from_numpy((self.cost.max(1) == self.cost.min(1)).astype(np.int32))
+        return m
+
+    def set_const_mask(self, mask):
+        self.cmask = mask.numpy().astype(bool)
 
     def new_keys(self):
         return torch.zeros(self.n + 16, dtype=torch.int64)
@@ -43,7 +55,7 @@ class ModelShard:
     def bid(self, rnd, keys):
         k = keys.numpy()
         owned = (self.owner >= 0).astype(np.int64)
-        for lr in np.nonzero(self.r2c < 0)[0]:
+        for lr in np.nonzero(self.r2c == -1)[0]:
             key = 2 * (self.cc[lr] + self.p) + owned
             rot = (int(lr + self.row0) * 7919 + rnd * 104729) % self.n
             order = np.roll(np.arange(self.n), -rot)
@@ -87,7 +99,10 @@ class ModelShard:
         p, owner = self.p, self.owner
         r2c = np.full(n, -1, np.int64)
         r2c[owner[owner >= 0]] = np.nonzero(owner >= 0)[0]
-        for f in np.nonzero(r2c < 0)[0]:
+        cmask = getattr(self, "cmask", None)
+        if cmask is None:
+            cmask = np.zeros(n, bool)
+        for f in np.nonzero((r2c < 0) & ~cmask)[0]:
             d = cc[f] + p
             pred = np.full(n, f, np.int64)
             scanned = np.zeros(n, bool)
@@ -109,6 +124,10 @@ class ModelShard:
                 j, r2c[i] = int(r2c[i]), j
                 if i == f:
                     break
+        # the deferred constant rows take the columns nobody owns, k-th row <- k-th free column
+        crow, fcol = np.nonzero(cmask)[0], np.nonzero(owner < 0)[0]
+        assert len(crow) == len(fcol)
+        owner[fcol] = crow
         self.set_owner(torch.from_numpy(owner.astype(np.int32)))
 
     def get_owner(self):

@@ -40,7 +40,12 @@ def _collect(q, procs, count, limit=240):
     return sorted(outs)
 
 
-def _worker(rank, world, port, n, seed, use_ipc, q):
+def _padded_rows(n, seed):
+    """rows of big_cost (dummy cabs, greedy_opt.py:88-90) in a uniform matrix: a third of the rows, anywhere"""
+    return np.random.default_rng(seed).permutation(n)[:n // 3]
+
+
+def _worker(rank, world, port, n, seed, use_ipc, q, kind="g1"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -53,7 +58,11 @@ def _worker(rank, world, port, n, seed, use_ipc, q):
     from oracle import oracle
     td.init(0)
     row0, nrows, rps = sharded.shard_bounds(n, world, rank)
-    rows = torch.from_numpy(oracle.gen_uniform(n, seed, 10, 40, row0, nrows)).cuda()
+    rows = oracle.gen_uniform(n, seed, 10, 40, row0, nrows)
+    if kind == "padded":
+        dummy = _padded_rows(n, seed)
+        rows[dummy[(dummy >= row0) & (dummy < row0 + nrows)] - row0] = 250000
+    rows = torch.from_numpy(rows).cuda()
     sh = sharded.HipShard(n, row0, nrows, rows)
     try:
         # three solves on one shard object, as a tick loop or bench.py does: the peer mapping of rank 1's shard is
@@ -74,14 +83,17 @@ def _worker(rank, world, port, n, seed, use_ipc, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,use_ipc", [(512, True), (2050, True), (1000, False)])
-def test_two_ranks_one_gpu(n, use_ipc):
+@pytest.mark.parametrize("n,use_ipc,kind", [(512, True, "g1"), (2050, True, "g1"), (1000, False, "g1"), (1500, True, "padded"),
+                                            (300, False, "padded")])
+def test_two_ranks_one_gpu(n, use_ipc, kind):
+    """kind "padded": a third of the rows are dummy cabs (constant rows): they sit out the rounds and the searches on
+    both ranks (td_shard_const_rows) and take the left-over columns on the finisher's rank"""
     from oracle import oracle
     seed = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, seed, use_ipc, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, seed, use_ipc, q, kind)) for r in range(2)]
     for p in procs:
         p.start()
     outs = _collect(q, procs, 2)
@@ -89,6 +101,8 @@ def test_two_ranks_one_gpu(n, use_ipc):
         p.join(timeout=120)
         assert p.exitcode == 0
     cost = oracle.gen_uniform(n, seed, 10, 40)
+    if kind == "padded":
+        cost[_padded_rows(n, seed)] = 250000
     ref = oracle.assign(cost)[0]
     r2c = np.array(outs[0][1] + outs[1][1])
     assert outs[0][2] == outs[1][2] == ref

@@ -34,6 +34,10 @@ def _instance(kind, n, seed):
         c[c >= 10] = 250000
         c[:, max(1, int(0.4 * n)):] = 250000
         return c
+    if kind == "padded":   # greedy_opt.py:88-90: fewer cabs than requests, the missing cabs are rows of big_cost
+        c = rng.integers(10, 41, (n, n)).astype(np.int32)
+        c[rng.permutation(n)[:n // 3]] = 250000
+        return c
     a, b = rng.integers(0, 10 * n, n), rng.integers(0, 10 * n, n)
     return np.abs(a[:, None] - b[None, :]).astype(np.int32)
 
@@ -81,7 +85,7 @@ def test_shard_bounds():
         assert len({rps for *_, rps in rows}) == 1
 
 
-@pytest.mark.parametrize("kind,n", [("g1", 96), ("g2", 61), ("g3", 80)])
+@pytest.mark.parametrize("kind,n", [("g1", 96), ("g2", 61), ("g3", 80), ("padded", 70)])
 def test_sharded_equals_single_and_oracle(kind, n):
     from oracle import oracle
     cost = _instance(kind, n, 5)

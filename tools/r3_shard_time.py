@@ -63,12 +63,17 @@ def run():
         for r in range(world):
             row0, nrows, rps = sharded.shard_bounds(n, world, r)
             rows = full[row0:row0 + nrows]
-            if builder == "gen":
+            if builder in ("gen", "padded"):
                 _, t = timed(lambda: _ffi.check(lib.td_gen_uniform(n, 7, 10, 40, row0, nrows, rows.data_ptr())))
             else:   # a general S x S table with perf.jl's value range: the shard builds its rows from the replicated positions
                 da, db = torch.from_numpy(a % S).cuda(), torch.from_numpy(b % S).cuda()
                 _, t = timed(lambda: _ffi.check(lib.td_cost_build_rows(da.data_ptr(), None, n, db.data_ptr(), None, n, table.data_ptr(), S, 250000, -1, 0,
                                                                        row0, nrows, rows.data_ptr())))
+            if builder == "padded":   # a third of the rows are dummy cabs (constant rows of big_cost)
+                dummy = torch.from_numpy(np.random.default_rng(5).permutation(n)[:n // 3]).cuda()
+                mine = dummy[(dummy >= row0) & (dummy < row0 + nrows)] - row0
+                rows[mine] = 250000
+                torch.cuda.synchronize()
             add("build", t)
             shards.append(sharded.HipShard(n, row0, nrows, rows, share_torch_stream=False))
         width = None
@@ -84,6 +89,14 @@ def run():
                     add("compress", t)
                 width = w
                 break
+        if os.environ.get("TD_DEFER_CONST", "1") != "0":
+            masks = [s.const_mask() for s in shards]
+            tot_mask = masks[0]
+            for m in masks[1:]:
+                tot_mask += m
+            torch.cuda.synchronize()
+            for s in shards:
+                s.set_const_mask(tot_mask)
         grange = max(s.range() for s in shards)
         for s in shards:
             _, t = timed(lambda: s.begin(grange))
