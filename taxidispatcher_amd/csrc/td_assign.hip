@@ -192,6 +192,7 @@ int g_sapx_slim_chunks = INT_MAX; // TD_SAPX_SLIM  1- / 2-byte rows with at leas
 int g_sapx_rows = 24;       // TD_SAPX_ROWS     ... half of that when at least this many rows are left for it
 int g_sap512 = 1;           // TD_SAP512        512-thread generic finisher (double register budget) for n <= 8192
 int g_psap_worth = 4;       // TD_PSAP_WORTH    rows a batch must commit on average for another group to be launched
+int g_bid0 = 0;             // TD_BID0          round 0's bids come out of the register-resident compress pass (td_assign, 1-byte attempt). Bit-identical, OFF: perf.jl n = 16 384 saves round 0's k_bid (-83 us) but the compress pass pays 216 -> 309 us (every wave runs its 32 memory operations one behind the other, so any work added per row adds to the pass: profiles/r3/README)
 int g_defer_const = 1;      // TD_DEFER_CONST   constant rows sit out the solve (k_place_const)
 int g_shape = 1;            // TD_SHAPE         probe for constant columns and solve the transpose when they dominate
 int g_shape_max_n = 1 << 20; // TD_SHAPE_MAX_N   largest n the probe runs for
@@ -253,6 +254,7 @@ void read_tunables()
     if (const char *e = getenv("TD_EPS_THETA")) g_eps_theta = std::max(2, atoi(e));
     if (const char *e = getenv("TD_PSAP8")) g_psap8_batches = std::max(0, std::min(32, atoi(e)));
     if (const char *e = getenv("TD_DEFER_CONST")) g_defer_const = atoi(e) != 0;
+    if (const char *e = getenv("TD_BID0")) g_bid0 = atoi(e) != 0;
     if (const char *e = getenv("TD_SHAPE")) g_shape = atoi(e) != 0;
     if (const char *e = getenv("TD_SHAPE_MAX_N")) g_shape_max_n = atoi(e);
     if (const char *e = getenv("TD_WIDE_U16_N")) g_wide_u16_n = std::max(0, atoi(e));
@@ -432,19 +434,69 @@ __global__ __launch_bounds__(256) void k_compress(int n, int nrows, int nchunks,
 // Register-resident variant: the row is read ONCE from HBM (all VPT 16-byte loads of a thread
 // are issued back to back, so a 256-thread workgroup keeps 64 KiB in flight), reduced, and
 // written back narrow.  Needs n % 4 == 0, a 16-byte aligned matrix and n/4 <= THREADS*VPT.
-template <typename CT, int VPT, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nrows, int nchunks, const int32_t *__restrict__ cost,
-                                                          CT *__restrict__ cc, int32_t *__restrict__ rowmin,
-                                                          int *__restrict__ ctl, int *__restrict__ rconst, const long long *__restrict__ skip)
+__device__ __forceinline__ void shape_decide(int n, int *__restrict__ ctl);
+
+// BID0: the row is in registers with its minimum known, so the bid of round 0 (all prices 0: the first minimum in
+// the row's rotated chunk order, raised by second smallest - smallest) is written here and the round's own pass over
+// the narrow matrix (k_bid, round 0) is not launched — the same key, bit for bit.
+template <typename CT, int VPT, int THREADS, bool BID0 = false>
+__global__ __launch_bounds__(THREADS, (THREADS == 256 && BID0) ? 4 : 1) void k_compress_reg(
+    int n, int nrows, int nchunks, const int32_t *__restrict__ cost, CT *__restrict__ cc, int32_t *__restrict__ rowmin, int *__restrict__ ctl,
+    int *__restrict__ rconst, const long long *__restrict__ skip, unsigned long long *__restrict__ bid = nullptr, int row0 = 0,
+    int *__restrict__ r2c = nullptr /* BID0: constant rows are deferred (-2) */,
+    int probe_tickets = 0 /* BID0: > 0 = take a ticket of the shape probe at the end */)
 {
+    static_assert(!BID0 || sizeof(CT) == 1, "round 0 out of the compress pass: 1-byte cells");
     if (skip && *skip) return;
     constexpr int E = Tr<CT>::E;
     constexpr int NW = THREADS / 64;
     __shared__ int s_mn[2][NW], s_mx[2][NW];
+    __shared__ int s_fp[2][BID0 ? NW : 1], s_c0[2][BID0 ? NW : 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const size_t pitch = (size_t)nchunks * E;
     const int nq = n >> 2;
     int par = 0;
+    // BID0: the bid of a row is issued one iteration LATER, behind the next row's barrier (the waves' summaries of the
+    // zero bytes they stored travel through LDS): no second barrier per row, which would also wait for the row's stores
+    int prev_row = -1, prev_rot = 0;
+    auto flush_bid = [&](int slot) {   // wave 0, after a barrier that follows the summaries of `prev_row` in s_fp / s_c0 [slot]
+        if constexpr (BID0) {
+            if (prev_row < 0 || w != 0) return;
+            int fp = INT_MAX, c0 = 0;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                fp = min(fp, s_fp[slot][k]);
+                c0 += s_c0[slot][k];
+            }
+            if (fp == INT_MAX) return;   // the row did not bid (deferred, or too wide for one byte)
+            unsigned m2 = 255;
+            if (c0 == 1) {   // (wave-uniform, rare in rows this wide) a single cell at the minimum: second smallest = the smallest non-zero byte of the row just written
+                // (agent-scope loads: the words were stored by the other waves of this workgroup before the barrier, their
+                // stores acknowledged by L2; the CU's L1 is not trusted to have seen them)
+                const uint32_t *rp = reinterpret_cast<const uint32_t *>(cc + (size_t)prev_row * pitch);
+                for (int q = lane; q < nchunks * 4; q += 64) {
+                    const uint32_t x = __hip_atomic_load(rp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const unsigned b = (x >> (8 * e)) & 0xFFu;
+                        m2 = (b != 0 && b < m2) ? b : m2;   // (pad cells hold the sentinel 255)
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m2 = min(m2, (unsigned)__shfl_xor((int)m2, o));
+            }
+            if (lane == 0) {
+                const int grow = row0 + prev_row;
+                const int t1 = fp / E;
+                int ch = t1 + prev_rot;
+                if (ch >= nchunks) ch -= nchunks;
+                const int j1 = ch * E + (fp - t1 * E);
+                const unsigned long long inc = (c0 >= 2 || m2 == 255) ? 0ull : (unsigned long long)m2;
+                if (inc == 0 && (grow & 15) == 0) atomicAdd(&ctl[CTL_TIED], 1);
+                if (j1 < n) atomicMax(&bid[j1], (inc << ROW_BITS) | (unsigned long long)(grow + 1));
+            }
+        }
+    };
     for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int4 *s4 = reinterpret_cast<const int4 *>(cost + (int64_t)row * n);
         int4 v[VPT];
@@ -480,20 +532,29 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nrows, int 
             s_mx[par][w] = mx;
         }
         __syncthreads();
+        flush_bid(par ^ 1);   // the previous row's summaries were written before this barrier
 #pragma unroll
         for (int k = 0; k < NW; k++) {
             mn = min(mn, s_mn[par][k]);
             mx = max(mx, s_mx[par][k]);
         }
-        par ^= 1;
+        const bool fits = (int64_t)mx - (int64_t)mn <= Tr<CT>::LIMIT;
         if (tid == 0) {
             rowmin[row] = mn;
             rconst[row] = (mx == mn) ? 1 : 0;   // a constant row can take ANY column at the same cost
             if (mx == mn) atomicAdd(&ctl[CTL_NCONST], 1);
-            if ((int64_t)mx - (int64_t)mn > Tr<CT>::LIMIT) {
+            if (!fits) {
                 atomicOr(&ctl[CTL_FLAG], 1);
                 atomicMax(reinterpret_cast<unsigned long long *>(&ctl[CTL_RANGE]), (unsigned long long)((int64_t)mx - (int64_t)mn));
             }
+        }
+        // BID0 (row-uniform): the narrow words are scanned for zero bytes (= cells at the row minimum) as they are stored
+        const bool deferred = BID0 && r2c && mx == mn;
+        const bool bids = BID0 && fits && !deferred;
+        int fp = INT_MAX, c0 = 0, rot = 0;
+        if constexpr (BID0) {
+            const uint32_t hsh = ((uint32_t)(row0 + row) + 1u) * 0x9E3779B1u;   // k_bid's rotation, round 0
+            rot = (int)(((uint64_t)(hsh ^ (hsh >> 15)) * (uint64_t)nchunks) >> 32);
         }
         CT *dst = cc + (size_t)row * pitch;
 #pragma unroll
@@ -503,7 +564,18 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nrows, int 
                 const uint32_t a = (uint32_t)(v[k].x - mn), b = (uint32_t)(v[k].y - mn), c = (uint32_t)(v[k].z - mn),
                                d = (uint32_t)(v[k].w - mn);
                 if constexpr (sizeof(CT) == 1) {
-                    reinterpret_cast<uint32_t *>(dst)[q] = (a & 0xFF) | ((b & 0xFF) << 8) | ((c & 0xFF) << 16) | (d << 24);
+                    const uint32_t word = (a & 0xFF) | ((b & 0xFF) << 8) | ((c & 0xFF) << 16) | (d << 24);
+                    reinterpret_cast<uint32_t *>(dst)[q] = word;
+                    if constexpr (BID0) {
+                        // 0x80 in every byte of `word` that is zero (exact: no borrow between bytes)
+                        // (branch-free: a divergent branch here makes the compiler wait for every store before the next)
+                        const uint32_t z = ~(((word & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | word | 0x7F7F7F7Fu);
+                        int t = (q >> 2) - rot;   // position of the word's chunk in the row's rotated order
+                        t += t < 0 ? nchunks : 0;
+                        const int cand = t * 16 + (q & 3) * 4 + (__builtin_ctz(z | 0x80000000u) >> 3);
+                        fp = min(fp, z ? cand : INT_MAX);
+                        c0 += __builtin_popcount(z);
+                    }
                 } else if constexpr (sizeof(CT) == 2) {
                     reinterpret_cast<uint2 *>(dst)[q] = make_uint2((a & 0xFFFF) | (b << 16), (c & 0xFFFF) | (d << 16));
                 } else {
@@ -513,18 +585,46 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(int n, int nrows, int 
         }
         // sentinel tail up to the 16-byte chunk boundary
         for (int j = n + tid; j < (int)pitch; j += THREADS) dst[j] = (CT)Tr<CT>::SENT;
+        if constexpr (BID0) {
+            if (deferred && tid == 0) r2c[row] = -2;
+            if (!bids) fp = INT_MAX, c0 = 0;   // (row-uniform)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                fp = min(fp, __shfl_xor(fp, o));
+                c0 += __shfl_xor(c0, o);
+            }
+            if (lane == 0) {
+                s_fp[par][w] = fp;
+                s_c0[par][w] = c0;
+            }
+            prev_row = row;
+            prev_rot = rot;
+        }
+        par ^= 1;
+    }
+    if constexpr (BID0) {
+        __syncthreads();   // (waits for the last row's stores too: the single-minimum path reads them back)
+        flush_bid(par ^ 1);
+        if (probe_tickets > 0) {   // the shape probe's column samples were taken by k_init_state, in front of this pass
+            __syncthreads();
+            if (tid == 0) {
+                __threadfence();
+                if (atomicAdd(&ctl[CTL_SHAPE + 2], 1) == probe_tickets - 1) shape_decide(n, ctl);
+            }
+        }
     }
 }
 
 // =====================================================================================
 // state init
 // =====================================================================================
-__device__ __forceinline__ void shape_probe(int n, const int32_t *__restrict__ cost, int *__restrict__ ctl);
+__device__ __forceinline__ void shape_probe(int n, const int32_t *__restrict__ cost, int *__restrict__ ctl, int tickets);
 
 template <typename PT>
 __global__ __launch_bounds__(256) void k_init_state(int n, int npad, int nrows, PT *pk, PT padkey, int *owner, int *r2c,
                                                     unsigned long long *bid, int *ctl, const int *rconst,
-                                                    const int32_t *probe_cost /* non-null: run the shape probe */)
+                                                    const int32_t *probe_cost /* non-null: run the shape probe */,
+                                                    int probe_tickets = 0 /* > 0: the compress pass that FOLLOWS takes tickets too and decides */)
 {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < npad) {
@@ -535,7 +635,7 @@ __global__ __launch_bounds__(256) void k_init_state(int n, int npad, int nrows, 
     // -1: free row; -2: constant row, deferred to k_place_const (never bids, never searched)
     if (j < nrows) r2c[j] = (rconst && rconst[j]) ? -2 : -1;
     if (j < CTL_WORDS && j != CTL_FLAG && j != CTL_NCONST && j != CTL_RANGE && j != CTL_RANGE + 1) ctl[j] = 0;
-    if (probe_cost) shape_probe(n, probe_cost, ctl);   // uniform: every workgroup takes part in the ticket
+    if (probe_cost) shape_probe(n, probe_cost, ctl, probe_tickets > 0 ? probe_tickets : (int)gridDim.x);   // uniform: every workgroup takes part in the ticket
 }
 
 // =====================================================================================
@@ -901,7 +1001,26 @@ __global__ __launch_bounds__(1024) void k_place_const(int n, int *__restrict__ r
 // constant ROWS, which are deferred. Sets CTL_FLAG bit 2 -> every later kernel of the attempt
 // exits, the host transposes and redoes. The probe only picks the cheaper of two exact
 // formulations; its estimate needs no guarantee.
-__device__ __forceinline__ void shape_probe(int n, const int32_t *__restrict__ cost, int *__restrict__ ctl)
+// the last ticket holder decides (the constant rows have been counted by then: by the compress pass before this
+// kernel, or — k_compress_reg<BID0>, which runs AFTER the state init — by the workgroups that took the other tickets)
+__device__ __forceinline__ void shape_decide(int n, int *__restrict__ ctl)
+{
+    int *sh = ctl + CTL_SHAPE;
+    __threadfence();
+    const int ncol = atomicAdd(&sh[0], 0);
+    const int nrow = atomicAdd(&ctl[CTL_NCONST], 0);
+    sh[1] = nrow;
+    // more constant columns than constant rows = more real rows than real columns: every surplus real row
+    // would need a search that scans all real columns before it reaches a dummy one (~30 us each, and too
+    // long a record for the speculative batches); in the transposed problem every real row finds a real column
+    const int margin = n / 256 > 32 ? n / 256 : 32;
+    if (ncol >= 16 && ncol - nrow >= margin) {
+        sh[3] = 1;
+        atomicOr(&ctl[CTL_FLAG], 4);
+    }
+}
+
+__device__ __forceinline__ void shape_probe(int n, const int32_t *__restrict__ cost, int *__restrict__ ctl, int tickets)
 {
     int *sh = ctl + CTL_SHAPE;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -934,23 +1053,10 @@ __device__ __forceinline__ void shape_probe(int n, const int32_t *__restrict__ c
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        s_last = (atomicAdd(&sh[2], 1) == (int)gridDim.x - 1);
+        s_last = (atomicAdd(&sh[2], 1) == tickets - 1);
     }
     __syncthreads();
-    if (s_last && threadIdx.x == 0) {
-        __threadfence();
-        const int ncol = atomicAdd(&sh[0], 0);
-        const int nrow = ctl[CTL_NCONST];
-        sh[1] = nrow;
-        // more constant columns than constant rows = more real rows than real columns: every surplus real row
-        // would need a search that scans all real columns before it reaches a dummy one (~30 us each, and too
-        // long a record for the speculative batches); in the transposed problem every real row finds a real column
-        const int margin = n / 256 > 32 ? n / 256 : 32;
-        if (ncol >= 16 && ncol - nrow >= margin) {
-            sh[3] = 1;
-            atomicOr(&ctl[CTL_FLAG], 4);
-        }
-    }
+    if (s_last && threadIdx.x == 0) shape_decide(n, ctl);
 }
 
 // out[j][i] = in[i][j], 64 x 64 tiles through LDS (both sides coalesced)
@@ -2774,6 +2880,8 @@ struct td_shard {
     int nconst = -1;                 // constant rows counted by the last compress pass (-1: not read back)
     const int32_t *probe = nullptr;  // non-null for the one k_init_state launch that carries the shape probe
     bool placed = false;       // ... and the finisher kernel has already placed them (no k_place_const launch)
+    bool want_bid0 = false;    // td_assign: let the compress pass write round 0's bids (k_compress_reg<BID0>)
+    bool bid0_done = false;    // ... it did: state init has run before the pass, round 0 launches no k_bid
     Buf cmask;                 // sharded solve: the replicated mask of constant rows (td_shard_const_rows)
     bool have_cmask = false;
     bool fused_t = false;      // cc holds the TRANSPOSED problem built straight from the caller's matrix (k_compress_tr): d_cost is not transposed
@@ -2833,12 +2941,31 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
     TD_HIP(hipMemsetAsync(ctl, 0, CTL_ALL * sizeof(int), c.stream));  // flag, error, stats, range, shape
     const bool vec = (n % 4 == 0) && (((uintptr_t)sv.d_cost & 15) == 0);
     const int grid = std::max(1, std::min(nrows, c.n_cu * 8));
+    sv.bid0_done = false;
     if (nrows > 0) {
-        ProfScope ps(TD_K_COMPRESS);
         const int nq = n / 4;
         CT *cc = (CT *)sv.cc.p;
         int32_t *rm = (int32_t *)sv.rowmin.p;
         int *rcs = (int *)sv.rconst.p;
+        // round 0's bids out of the compress pass: the state is initialised BEFORE it (bid keys zeroed, rows free; the
+        // pass itself marks the deferred constant rows), td_assign then skips sv_begin_t and round 0's k_bid
+        const bool bid0 = sv.want_bid0 && g_bid0 && sizeof(CT) == 1 && g_creg && vec && nq > 2048 && nq <= 1024 * 16;
+        int tickets = 0;
+        if (bid0) {
+            using PT = typename Tr<CT>::PT;
+            const int npad = nchunks * E;
+            const PT padkey = (PT)(Tr<CT>::BIG << 1) | (PT)1;
+            const int gi = (std::max(npad, (int)CTL_WORDS) + 255) / 256;
+            const int gc = nq <= 256 * 16 ? std::max(1, std::min(nrows, c.n_cu * g_cgrid)) : std::max(1, std::min(nrows, c.n_cu * 2));
+            tickets = sv.probe ? gi + gc : 0;
+            k_init_state<PT><<<gi, 256, 0, c.stream>>>(n, npad, nrows, (PT *)sv.price.p, padkey, (int *)sv.owner.p, (int *)sv.r2c.p,
+                                                       (unsigned long long *)sv.bid.p, ctl, nullptr, sv.probe, tickets);
+            TD_HIP(hipMemsetAsync((char *)sv.misc.p + 1024, 0, 16, c.stream));
+            sv.bid0_done = true;
+        }
+        ProfScope ps(TD_K_COMPRESS);
+        unsigned long long *bidp = (unsigned long long *)sv.bid.p;
+        int *defer_r2c = sv.defer_const ? (int *)sv.r2c.p : nullptr;
         if (g_creg && vec && nq <= 256 * 16) {
             const int g2 = std::max(1, std::min(nrows, c.n_cu * g_cgrid));
 #define TD_CR(VPT) k_compress_reg<CT, VPT, 256><<<g2, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip)
@@ -2846,10 +2973,20 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
             else if (nq <= 512) { TD_CR(2); }
             else if (nq <= 1024) { TD_CR(4); }
             else if (nq <= 2048) { TD_CR(8); }
-            else { TD_CR(16); }
+            else if (bid0) {
+                if constexpr (sizeof(CT) == 1)
+                    k_compress_reg<CT, 16, 256, true><<<g2, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
+                                                                                sv.row0, defer_r2c, tickets);
+            } else { TD_CR(16); }
 #undef TD_CR
         } else if (g_creg && vec && nq <= 1024 * 16) {
-            k_compress_reg<CT, 16, 1024><<<std::max(1, std::min(nrows, c.n_cu * 2)), 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip);
+            const int g4 = std::max(1, std::min(nrows, c.n_cu * 2));
+            if (bid0) {
+                if constexpr (sizeof(CT) == 1)
+                    k_compress_reg<CT, 16, 1024, true><<<g4, 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
+                                                                                  sv.row0, defer_r2c, tickets);
+            } else
+                k_compress_reg<CT, 16, 1024><<<g4, 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip);
         } else if (vec)
             k_compress<CT, true><<<grid, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip);
         else
@@ -3521,6 +3658,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     bool solved = false, transposed = false, np_failed = false, no_fuse = false, fused_spec = false;
     int64_t range_hint = -1;
     sv.defer_const = g_defer_const && !g_solver_eps;
+    sv.bid0_done = false;
     int64_t hinted_range = -1;
     if (hinted_fuse) {   // the caller (td_tick) told the shape: the fused pass at once, speculatively (flags with the final read-back)
         bool ff = false;
@@ -3555,11 +3693,19 @@ restart:
         const bool spec = (bpc == 1) && g_speculate;
     compress_pass:
         if (sv.fused_t) {   // cc already holds the transposed problem (k_compress_tr); the same bytes serve both price widths
+            sv.bid0_done = false;   // (a 1-byte attempt queued before the fused pass may have set it)
             fits = true;
             sv.bpc = bpc;
             if (np_failed) k_fill_i32<<<1, 64, 0, c.stream>>>((int *)sv.misc.p + CTL_FLAG, 2, 0);   // the price-limit flag of the 32-bit attempt
-        } else if ((rc = sv_compress(sv, bpc, &fits, spec)))
-            return rc;
+        } else {
+            // 1-byte attempt: state init + the shape probe ride in front of the compress pass, which writes round 0's bids
+            sv.want_bid0 = spec && !g_solver_eps;
+            sv.probe = (spec && orient == 0 && g_shape && n >= 64 && n <= g_shape_max_n && !g_solver_eps) ? sv.d_cost : nullptr;
+            rc = sv_compress(sv, bpc, &fits, spec);
+            sv.want_bid0 = false;
+            sv.probe = nullptr;
+            if (rc) return rc;
+        }
         if (line_pending) {
             line_pending = false;
             sv.skip = nullptr;
@@ -3650,7 +3796,8 @@ restart:
         // shape probe (inside k_init_state): may ask (CTL_FLAG bit 2) for the transposed formulation;
         // like a failed width speculation this costs one empty pass through the early-exiting kernels
         sv.probe = (spec && orient == 0 && g_shape && n >= 64 && n <= g_shape_max_n && !g_solver_eps) ? sv.d_cost : nullptr;
-        TD_DISPATCH(sv, sv_begin_t, sv);
+        rc = TD_OK;
+        if (!sv.bid0_done) TD_DISPATCH(sv, sv_begin_t, sv);
         sv.probe = nullptr;
         if (rc) return rc;
         if (spec && early_check) {
@@ -3689,9 +3836,10 @@ restart:
             solved = true;
             break;
         }
-        auto rounds = [&](bool) -> int {
+        auto rounds = [&](bool first) -> int {
             for (int r = 0; r < max_rounds; r++) {
-                TD_DISPATCH(sv, sv_bid_t, sv, r, (unsigned long long *)sv.bid.p);
+                rc = TD_OK;
+                if (!(r == 0 && first && sv.bid0_done)) TD_DISPATCH(sv, sv_bid_t, sv, r, (unsigned long long *)sv.bid.p);
                 if (rc) return rc;
                 TD_DISPATCH(sv, sv_apply_t, sv, r, (unsigned long long *)sv.bid.p);
                 if (rc) return rc;

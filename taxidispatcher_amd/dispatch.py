@@ -280,6 +280,8 @@ def find_pool_n(k, demand, distances=None, child=None, children=8, max_happy=0):
     (pool_n.c:243-246); None: all requests as first pick-up.  Returns (int32 array [m, 2k+1] of
     pick-ups, drop-offs, cost in the reference's output order, number of happy plans)."""
     lib = _ffi.lib()
+    if not 2 <= int(k) <= 4:
+        raise _ffi.TdError("pool size %d (2..4)" % int(k))
     d = _ffi.as_i32(np.asarray(demand).reshape(len(demand), -1))
     n = int(d.shape[0])
     frm, to, wait, loss = (np.ascontiguousarray(d[:, c]) for c in (1, 2, 3, 4))

@@ -24,7 +24,17 @@ def random_demand(rng, n, max_wait, losses, stands=50):
     return np.stack([np.arange(n), frm, to, rng.integers(0, max_wait + 1, n), rng.choice(losses, n)], 1)
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 4])
+def test_pool_size_outside_2_to_4_is_refused(td):
+    """with k = 1 the reference's duplicate test compares padded slots (pool_n.c:175-193); the library refuses
+    the sizes it cannot answer like the reference instead of answering differently"""
+    from taxidispatcher_amd import _ffi
+    d = random_demand(np.random.default_rng(1), 20, 5, [50])
+    for k in (0, 1, 5):
+        with pytest.raises(_ffi.TdError):
+            td.find_pool_n(k, d)
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
 def test_pool_n_random_vs_oracle(td, k):
     rng = np.random.default_rng(40 + k)
     for n, mw, losses in ((4, 9, [90]), (17, 5, [10, 50]), (150, 3, [1, 30]), (600, 1 if k == 4 else 2, [1, 5, 20])):
