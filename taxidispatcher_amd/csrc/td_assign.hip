@@ -192,7 +192,7 @@ int g_sapx_slim_chunks = INT_MAX; // TD_SAPX_SLIM  1- / 2-byte rows with at leas
 int g_sapx_rows = 24;       // TD_SAPX_ROWS     ... half of that when at least this many rows are left for it
 int g_sap512 = 1;           // TD_SAP512        512-thread generic finisher (double register budget) for n <= 8192
 int g_psap_worth = 4;       // TD_PSAP_WORTH    rows a batch must commit on average for another group to be launched
-int g_bid0 = 0;             // TD_BID0          round 0's bids come out of the register-resident compress pass (td_assign, 1-byte attempt). Bit-identical, OFF: perf.jl n = 16 384 saves round 0's k_bid (-83 us) but the compress pass pays 216 -> 309 us (every wave runs its 32 memory operations one behind the other, so any work added per row adds to the pass: profiles/r3/README)
+int g_bid0 = 1;             // TD_BID0          round 0's bids come out of the register-resident compress pass (td_assign, 1-byte attempt; k_compress_reg<.., BID0>): perf.jl n = 16 384 step 0.870 -> 0.809 ms
 int g_defer_const = 1;      // TD_DEFER_CONST   constant rows sit out the solve (k_place_const)
 int g_shape = 1;            // TD_SHAPE         probe for constant columns and solve the transpose when they dominate
 int g_shape_max_n = 1 << 20; // TD_SHAPE_MAX_N   largest n the probe runs for
@@ -440,7 +440,7 @@ __device__ __forceinline__ void shape_decide(int n, int *__restrict__ ctl);
 // the row's rotated chunk order, raised by second smallest - smallest) is written here and the round's own pass over
 // the narrow matrix (k_bid, round 0) is not launched — the same key, bit for bit.
 template <typename CT, int VPT, int THREADS, bool BID0 = false>
-__global__ __launch_bounds__(THREADS, (THREADS == 256 && BID0) ? 4 : 1) void k_compress_reg(
+__global__ __launch_bounds__(THREADS) void k_compress_reg(
     int n, int nrows, int nchunks, const int32_t *__restrict__ cost, CT *__restrict__ cc, int32_t *__restrict__ rowmin, int *__restrict__ ctl,
     int *__restrict__ rconst, const long long *__restrict__ skip, unsigned long long *__restrict__ bid = nullptr, int row0 = 0,
     int *__restrict__ r2c = nullptr /* BID0: constant rows are deferred (-2) */,
@@ -2949,14 +2949,16 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
         int *rcs = (int *)sv.rconst.p;
         // round 0's bids out of the compress pass: the state is initialised BEFORE it (bid keys zeroed, rows free; the
         // pass itself marks the deferred constant rows), td_assign then skips sv_begin_t and round 0's k_bid
-        const bool bid0 = sv.want_bid0 && g_bid0 && sizeof(CT) == 1 && g_creg && vec && nq > 2048 && nq <= 1024 * 16;
+        const bool bid0 = sv.want_bid0 && g_bid0 && sizeof(CT) == 1 && g_creg && vec && nq >= 3072 && nq <= 1024 * 16;   // n >= 12 288 (n = 9000: 0.52 -> 0.56 ms, the pass has too few rows per CU to hide the scan)
         int tickets = 0;
+        static const int gbm = getenv("TD_BID0_GRID") ? atoi(getenv("TD_BID0_GRID")) : 0;
+        const int gb = std::max(1, std::min(nrows, c.n_cu * (gbm > 0 ? gbm : std::max(1, g_cgrid / 2))));   // 512-thread workgroups of the BID0 pass
         if (bid0) {
             using PT = typename Tr<CT>::PT;
             const int npad = nchunks * E;
             const PT padkey = (PT)(Tr<CT>::BIG << 1) | (PT)1;
             const int gi = (std::max(npad, (int)CTL_WORDS) + 255) / 256;
-            const int gc = nq <= 256 * 16 ? std::max(1, std::min(nrows, c.n_cu * g_cgrid)) : std::max(1, std::min(nrows, c.n_cu * 2));
+            const int gc = nq <= 256 * 16 ? gb : std::max(1, std::min(nrows, c.n_cu * 2));
             tickets = sv.probe ? gi + gc : 0;
             k_init_state<PT><<<gi, 256, 0, c.stream>>>(n, npad, nrows, (PT *)sv.price.p, padkey, (int *)sv.owner.p, (int *)sv.r2c.p,
                                                        (unsigned long long *)sv.bid.p, ctl, nullptr, sv.probe, tickets);
@@ -2974,10 +2976,24 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
             else if (nq <= 1024) { TD_CR(4); }
             else if (nq <= 2048) { TD_CR(8); }
             else if (bid0) {
-                if constexpr (sizeof(CT) == 1)
-                    k_compress_reg<CT, 16, 256, true><<<g2, 256, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
-                                                                                sv.row0, defer_r2c, tickets);
-            } else { TD_CR(16); }
+                // 512 threads x 8 pieces: half the row registers per thread, so that the zero-byte scan fits without giving up waves
+                if constexpr (sizeof(CT) == 1) {
+                    static const int shape = getenv("TD_BID0_SHAPE") ? atoi(getenv("TD_BID0_SHAPE")) : 0;
+                    if (shape == 1)
+                        k_compress_reg<CT, 4, 1024, true><<<gb, 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
+                                                                                    sv.row0, defer_r2c, tickets);
+                    else
+                        k_compress_reg<CT, 8, 512, true><<<gb, 512, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
+                                                                                   sv.row0, defer_r2c, tickets);
+                }
+            } else {
+                static const int cshape = getenv("TD_CREG_SHAPE") ? atoi(getenv("TD_CREG_SHAPE")) : 0;
+                if (cshape == 1)
+                    k_compress_reg<CT, 8, 512><<<gb, 512, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip);
+                else if (cshape == 2)
+                    k_compress_reg<CT, 4, 1024><<<gb, 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip);
+                else { TD_CR(16); }
+            }
 #undef TD_CR
         } else if (g_creg && vec && nq <= 1024 * 16) {
             const int g4 = std::max(1, std::min(nrows, c.n_cu * 2));
