@@ -227,6 +227,9 @@ TD_API int td_gen_uniform(int n, uint64_t seed, int32_t lo, int32_t hi, int row0
  *                       td_assign: after td_shard_compress, before td_shard_begin, every rank marks its constant
  *                       rows in a zeroed device mask of n ints (set = 0), the caller SUM-all-reduces the mask and
  *                       gives it back (set = 1); the finisher's rank then hands those rows the left-over columns
+ *   td_shard_options    flags bit 0 = "this caller runs td_shard_const_rows in every solve": a wide shard's 1-byte
+ *                       compress pass may then initialise the state, defer the constant rows and write round 0's
+ *                       bids itself, as td_assign does (same keys; td_shard_bid(0) only hands them over)
  *   td_shard_bid        one Jacobi bidding round over the local free rows; writes keys[j] =
  *                       (price << 20 | global_row + 1) with atomicMax, 0 = no bid
  *   td_shard_apply      applies the globally reduced keys (identical on every rank) and zeroes them
@@ -262,6 +265,7 @@ TD_API int td_shard_owner(td_shard *s, int32_t *owner, int set);
 TD_API int td_shard_price(td_shard *s, int64_t *price /* n, device */, int set);
 TD_API int td_shard_total(td_shard *s, int64_t *partial_total, int64_t *partial_dual);
 TD_API int td_shard_const_rows(td_shard *s, int32_t *mask_full, int set);
+TD_API int td_shard_options(td_shard *s, int flags);
 TD_API int td_shard_row_to_col(td_shard *s, int32_t *r2c_local);
 /* The sorted matching of td_assign's line-metric path (cost = |a_i - b_j|, perf.jl's G2 family) over ROW SHARDS.
  * Replaces the same call as td_assign (simulator.py:199 / munkres.c solve / greedy_opt.py:95), for matrices one

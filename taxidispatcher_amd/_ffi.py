@@ -80,6 +80,7 @@ SIGNATURES = {
     "td_shard_total": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "td_shard_row_to_col": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
     "td_shard_const_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "td_shard_options": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "td_line_shard_ws_words": (ctypes.c_int64, [ctypes.c_int]),
     "td_line_shard_phase": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),

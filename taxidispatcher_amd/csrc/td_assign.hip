@@ -4087,6 +4087,19 @@ int td_shard_const_rows(td_shard *s, int32_t *mask_full, int set)
     return TD_OK;
 }
 
+// flags bit 0: the caller runs the constant-row exchange (td_shard_const_rows) in every solve — then the 1-byte
+// compress pass of a wide shard may initialise the state itself, defer its constant rows and write round 0's bids
+// (k_compress_reg<.., BID0>, as td_assign does); td_shard_begin / td_shard_bid(0) / td_shard_rounds then only hand the
+// prepared keys over.  Same keys bit for bit, so a sharded run stays identical to td_assign.
+int td_shard_options(td_shard *s, int flags)
+{
+    TD_REQUIRE_INIT();
+    if (!s) return fail(TD_EINVAL, "null shard");
+    s->want_bid0 = (flags & 1) != 0 && !g_solver_eps;
+    if (s->want_bid0) s->defer_const = g_defer_const && !g_solver_eps;
+    return TD_OK;
+}
+
 int td_shard_range(td_shard *s, int64_t *range)
 {
     TD_REQUIRE_INIT();
@@ -4104,21 +4117,35 @@ int td_shard_begin(td_shard *s, int64_t global_range)
     // the keys also travel through a signed 64-bit MAX all-reduce
     if ((double)(range + 1) * (double)(s->n + 1) >= 4.0e12)
         return fail(TD_ERANGE, "row cost range %lld with n=%d overflows the packed bid key (price < 2^43)", (long long)range, s->n);
-    int rc;
-    TD_DISPATCH(*s, sv_begin_t, *s);
+    int rc = TD_OK;
+    if (!s->bid0_done) TD_DISPATCH(*s, sv_begin_t, *s);   // (else the compress pass has initialised the state in front of itself)
     return rc;
 }
 
 int td_shard_keys_len(td_shard *s) { return s ? s->npad : 0; }
+
+namespace {
+// one bidding round of a shard; round 0 of a shard whose compress pass wrote the bids: hand them over
+int shard_bid_round(td_shard *s, int round, unsigned long long *keys)
+{
+    int rc = TD_OK;
+    if (round == 0 && s->bid0_done) {
+        const size_t bytes = sizeof(unsigned long long) * (size_t)s->npad;
+        TD_HIP(hipMemcpyAsync(keys, s->bid.p, bytes, hipMemcpyDeviceToDevice, ctx().stream));
+        TD_HIP(hipMemsetAsync(s->bid.p, 0, bytes, ctx().stream));   // the finisher's speculative batches use this buffer as zeroed scratch
+        return TD_OK;
+    }
+    TD_DISPATCH(*s, sv_bid_t, *s, round, keys);
+    return rc;
+}
+}  // namespace
 
 int td_shard_bid(td_shard *s, int round, uint64_t *keys)
 {
     TD_REQUIRE_INIT();
     if (!s || !keys) return fail(TD_EINVAL, "null argument");
     if (!is_device_ptr(keys)) return fail(TD_EINVAL, "bid keys must be device memory");
-    int rc;
-    TD_DISPATCH(*s, sv_bid_t, *s, round, (unsigned long long *)keys);
-    return rc;
+    return shard_bid_round(s, round, (unsigned long long *)keys);
 }
 
 int td_shard_apply(td_shard *s, int round, uint64_t *keys)
@@ -4226,8 +4253,7 @@ int td_shard_rounds(td_shard *s, int rounds, uint64_t *keys)
     int rc = TD_OK;
     static const bool force_ar = getenv("TD_SHARD_FORCE_AR") != nullptr;   // measurement: all-reduce with one rank too
     for (int r = 0; r < rounds; r++) {
-        TD_DISPATCH(*s, sv_bid_t, *s, r, (unsigned long long *)keys);
-        if (rc) return rc;
+        if ((rc = shard_bid_round(s, r, (unsigned long long *)keys))) return rc;
         if (g_rccl.world > 1 || force_ar) {
             const int e = g_rccl.AllReduce(keys, keys, (size_t)s->npad, RCCL_UINT64, RCCL_MAX, g_rccl.comm, c.stream);
             if (e) return rccl_fail(e, "ncclAllReduce");

@@ -239,6 +239,11 @@ class HipShard:
     def scalar_tensor(self, values, dtype=None):
         return self.torch.tensor(values, dtype=dtype or self.torch.int64, device=self.device)
 
+    def fused_round0(self, on=True):
+        """the caller promises the constant-row exchange in every solve: a wide shard's compress pass may write round 0's
+        bids itself (td_shard_options)"""
+        _ffi.check(self.lib.td_shard_options(self.h, 1 if on else 0))
+
     # -- constant rows sit out the solve (td_shard_const_rows)
     def const_mask(self):
         """zeroed device mask of n ints with this shard's constant rows set (after compress); the caller sums it"""
@@ -387,6 +392,9 @@ def _solve_sharded(shard, dist, rounds, want_dual, use_ipc):
             total, (r2c,) = got
             return (r2c, total, total) if want_dual else (r2c, total)
     # 1. agree on the storage width (every rank must use the same one)
+    defer = hasattr(shard, "const_mask") and os.environ.get("TD_DEFER_CONST", "1") != "0"
+    if hasattr(shard, "fused_round0"):
+        shard.fused_round0(defer)   # round 0 out of the compress pass needs the constant-row exchange below
     for width in (1, 2, 4):
         flag = shard.scalar_tensor([1 if shard.compress(width) else 0])
         if world > 1:
@@ -397,7 +405,7 @@ def _solve_sharded(shard, dist, rounds, want_dual, use_ipc):
         raise _ffi.TdError("row cost range exceeds 2^32-2 on some rank")
     # constant rows (dummy cabs of a padded model) sit out the rounds and the searches, as in td_assign: one SUM
     # all-reduce of an n-int mask tells every rank (the finisher's above all) which rows they are
-    if hasattr(shard, "const_mask") and os.environ.get("TD_DEFER_CONST", "1") != "0":
+    if defer:
         mask = shard.const_mask()
         if world > 1:
             all_reduce(dist, mask, SUM)

@@ -166,9 +166,17 @@ def test_config3_shard_geometry_in_process(td):
         for r in range(world):
             row0, nrows, rps = sharded.shard_bounds(n, world, r)
             shards.append(sharded.HipShard(n, row0, nrows, full[row0:row0 + nrows], share_torch_stream=False))
+        for s in shards:
+            s.fused_round0(True)   # as solve_sharded does: round 0's bids come out of the shards' compress passes
         for width in (1, 2, 4):
             if all([s.compress(width) for s in shards]):
                 break
+        masks = [s.const_mask() for s in shards]
+        for m in masks[1:]:
+            masks[0] += m
+        torch.cuda.synchronize()
+        for s in shards:
+            s.set_const_mask(masks[0])
         grange = max(s.range() for s in shards)
         for s in shards:
             s.begin(grange)

@@ -411,3 +411,82 @@ def test_solve_sharded_takes_the_line_path_under_rccl(td):
     p.join(timeout=60)
     assert status == "ok", out
     assert out[0] == "line"
+
+
+def _drive_shards_in_process(torch, sharded, full, n, world, fused):
+    """the steps of solve_sharded over `world` shards in one process (torch.maximum = the MAX all-reduce)"""
+    shards = []
+    try:
+        for r in range(world):
+            row0, nrows, rps = sharded.shard_bounds(n, world, r)
+            shards.append(sharded.HipShard(n, row0, nrows, full[row0:row0 + nrows], share_torch_stream=False))
+        for s in shards:
+            s.fused_round0(fused)
+        for width in (1, 2, 4):
+            if all([s.compress(width) for s in shards]):
+                break
+        masks = [s.const_mask() for s in shards]
+        for m in masks[1:]:
+            masks[0] += m
+        torch.cuda.synchronize()
+        for s in shards:
+            s.set_const_mask(masks[0])
+        grange = max(s.range() for s in shards)
+        for s in shards:
+            s.begin(grange)
+        keys = [s.new_keys() for s in shards]
+        for rnd in range(sharded.DEFAULT_ROUNDS):
+            for s, k in zip(shards, keys):
+                s.bid(rnd, k)
+            red = keys[0].clone()
+            for k in keys[1:]:
+                red = torch.maximum(red, k)
+            torch.cuda.synchronize()
+            for s, k in zip(shards, keys):
+                k.copy_(red)
+                torch.cuda.synchronize()
+                s.apply(rnd, k)
+        shards[0].finish([s.cc_ref() for s in shards], rps)
+        owner, price = shards[0].get_owner(), shards[0].get_price()
+        torch.cuda.synchronize()
+        tot = dual = 0
+        parts = []
+        for s in shards:
+            if s is not shards[0]:
+                s.set_owner(owner)
+                s.set_price(price)
+            t, d = s.totals(True)
+            tot += t
+            dual += d
+            parts.append(s.row_to_col())
+        return np.concatenate(parts), tot, dual
+    finally:
+        for s in shards:
+            s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["g1", "padded", "uniq"])
+def test_fused_round0_in_shards_is_bit_identical(td, kind):
+    """td_shard_options: a wide shard's 1-byte compress pass writes round 0's bids (k_compress_reg<.., BID0>) and defers
+    its constant rows; the run must equal the run with round 0 as its own k_bid launch AND td_assign, bit for bit"""
+    import torch
+    from taxidispatcher_amd import sharded
+    n, world = 12288, 3
+    g = torch.Generator(device="cuda").manual_seed(11)
+    if kind == "uniq":
+        full = torch.randint(3, 200, (n, n), dtype=torch.int32, device="cuda", generator=g)
+        full[torch.arange(n, device="cuda"), torch.randint(0, n, (n,), device="cuda", generator=g)] = 0
+    else:
+        full = torch.randint(10, 41, (n, n), dtype=torch.int32, device="cuda", generator=g)
+        if kind == "padded":
+            full[torch.randperm(n, device="cuda", generator=g)[: n // 4]] = 250
+    a = _drive_shards_in_process(torch, sharded, full, n, world, True)
+    b = _drive_shards_in_process(torch, sharded, full, n, world, False)
+    assert a[1] == a[2] == b[1] == b[2]
+    assert np.array_equal(a[0], b[0])
+    ref, ref_total, ref_dual = td.assign(full, want_dual=True)
+    assert ref_total == a[1] == ref_dual
+    if kind != "padded":    # (td_assign may solve a padded model transposed: another optimum among the ties)
+        assert np.array_equal(ref, a[0])
+    assert sorted(a[0].tolist()) == list(range(n))

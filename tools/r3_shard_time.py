@@ -76,6 +76,8 @@ def run():
                 torch.cuda.synchronize()
             add("build", t)
             shards.append(sharded.HipShard(n, row0, nrows, rows, share_torch_stream=False))
+        for s in shards:
+            s.fused_round0(os.environ.get("TD_SHARD_FUSED0", "1") != "0")
         width = None
         for w in (1, 2, 4):
             oks = []
