@@ -152,7 +152,8 @@ enum {
     CTL_PSTOP = CTL_WORDS + 6,
     CTL_TIED = CTL_WORDS + 7,    // rows whose two smallest costs are equal (bidding round 0, every 16th row sampled)   // a speculative batch committed nothing: later batches of the group exit at once
     CTL_FOREST = CTL_WORDS + 8,  // levels of the incremental forest finisher (0: another finisher ran)
-    CTL_ALL = CTL_WORDS + 9
+    CTL_RSEEN = CTL_WORDS + 10,  // [+10..11] 64-bit largest row range seen by the row-wise compress passes (whether it fits or not)
+    CTL_ALL = CTL_WORDS + 12
 };
 
 constexpr int ROW_BITS = 20;
@@ -172,6 +173,7 @@ int g_sap8 = 1;             // TD_SAP8          lean u8 finisher
 int g_psap8_batches = 1;    // TD_PSAP8         speculative batches of the lean u8 search
 int g_psap8_grid = 64;      // TD_PSAP8_GRID    searches per such batch
 int g_warm_tie_div = 2;     // TD_WARM_TIE_DIV  no warm start when more than n / this rows are tied at their minimum
+int g_u16_redo_free = 0;     // TD_U16_REDO_FREE 2-byte rows that leave at least this many free rows after the eps = 0 rounds are redone as 4-byte cells (forest finisher) even when too many rows are tied for the warm start (0: off)
 int g_wide_u16_n = 2048;    // TD_WIDE_U16_N    wide, tie-free 2-byte rows of n >= this are redone as 4-byte cells with 32-bit prices (0: never); 4096 until the forest finisher took n >= 2048 (2-D Manhattan n = 2500 / 3500: 31 -> 21 ms, 46 -> 21 ms; uniform 0..40 000 n = 3000: 6.6 -> 7.1 ms)
 bool g_line = true;         // TD_LINE          0: skip the line-metric recogniser (td_line.hip), always run the general solver
 int g_line_min_n = 2;       // TD_LINE_MIN_N    smallest n the recogniser is tried on
@@ -258,6 +260,7 @@ void read_tunables()
     if (const char *e = getenv("TD_SHAPE")) g_shape = atoi(e) != 0;
     if (const char *e = getenv("TD_SHAPE_MAX_N")) g_shape_max_n = atoi(e);
     if (const char *e = getenv("TD_WIDE_U16_N")) g_wide_u16_n = std::max(0, atoi(e));
+    if (const char *e = getenv("TD_U16_REDO_FREE")) g_u16_redo_free = std::max(0, atoi(e));
     if (const char *e = getenv("TD_WARM_TIE_DIV")) g_warm_tie_div = std::max(1, atoi(e));
     if (const char *e = getenv("TD_LINE")) g_line = atoi(e) != 0;
     if (const char *e = getenv("TD_LINE_MIN_N")) g_line_min_n = std::max(2, atoi(e));
@@ -351,6 +354,7 @@ __global__ __launch_bounds__(256) void k_compress(int n, int nrows, int nchunks,
     __shared__ int s_mn[4], s_mx[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const size_t pitch = (size_t)nchunks * E;
+    long long wmax = 0;   // largest row range of this workgroup's rows (thread 0)
     for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int32_t *src = cost + (int64_t)row * n;
         int mn = INT_MAX, mx = INT_MIN;
@@ -385,6 +389,7 @@ __global__ __launch_bounds__(256) void k_compress(int n, int nrows, int nchunks,
             rowmin[row] = mn;
             rconst[row] = (mx == mn) ? 1 : 0;   // a constant row can take ANY column at the same cost
             if (mx == mn) atomicAdd(&ctl[CTL_NCONST], 1);
+            wmax = std::max(wmax, (long long)mx - (long long)mn);
             if ((int64_t)mx - (int64_t)mn > Tr<CT>::LIMIT) {
                 atomicOr(&ctl[CTL_FLAG], 1);
                 atomicMax(reinterpret_cast<unsigned long long *>(&ctl[CTL_RANGE]), (unsigned long long)((int64_t)mx - (int64_t)mn));
@@ -429,6 +434,7 @@ __global__ __launch_bounds__(256) void k_compress(int n, int nrows, int nchunks,
             reinterpret_cast<uint4 *>(dst)[k] = pk;
         }
     }
+    if (tid == 0 && wmax > 0) atomicMax(reinterpret_cast<unsigned long long *>(&ctl[CTL_RSEEN]), (unsigned long long)wmax);
 }
 
 // Register-resident variant: the row is read ONCE from HBM (all VPT 16-byte loads of a thread
@@ -459,6 +465,7 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(
     // BID0: the bid of a row is issued one iteration LATER, behind the next row's barrier (the waves' summaries of the
     // zero bytes they stored travel through LDS): no second barrier per row, which would also wait for the row's stores
     int prev_row = -1, prev_rot = 0;
+    long long wmax = 0;   // largest row range of this workgroup's rows (thread 0)
     auto flush_bid = [&](int slot) {   // wave 0, after a barrier that follows the summaries of `prev_row` in s_fp / s_c0 [slot]
         if constexpr (BID0) {
             if (prev_row < 0 || w != 0) return;
@@ -543,6 +550,7 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(
             rowmin[row] = mn;
             rconst[row] = (mx == mn) ? 1 : 0;   // a constant row can take ANY column at the same cost
             if (mx == mn) atomicAdd(&ctl[CTL_NCONST], 1);
+            wmax = std::max(wmax, (long long)mx - (long long)mn);
             if (!fits) {
                 atomicOr(&ctl[CTL_FLAG], 1);
                 atomicMax(reinterpret_cast<unsigned long long *>(&ctl[CTL_RANGE]), (unsigned long long)((int64_t)mx - (int64_t)mn));
@@ -602,6 +610,7 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(
         }
         par ^= 1;
     }
+    if (tid == 0 && wmax > 0) atomicMax(reinterpret_cast<unsigned long long *>(&ctl[CTL_RSEEN]), (unsigned long long)wmax);
     if constexpr (BID0) {
         __syncthreads();   // (waits for the last row's stores too: the single-minimum path reads them back)
         flush_bid(par ^ 1);
@@ -2880,6 +2889,7 @@ struct td_shard {
     int nconst = -1;                 // constant rows counted by the last compress pass (-1: not read back)
     const int32_t *probe = nullptr;  // non-null for the one k_init_state launch that carries the shape probe
     bool placed = false;       // ... and the finisher kernel has already placed them (no k_place_const launch)
+    int64_t range_seen = -1;   // largest row range measured by the last synchronous compress pass
     bool want_bid0 = false;    // td_assign: let the compress pass write round 0's bids (k_compress_reg<BID0>)
     bool bid0_done = false;    // ... it did: state init has run before the pass, round 0 launches no k_bid
     Buf cmask;                 // sharded solve: the replicated mask of constant rows (td_shard_const_rows)
@@ -3015,10 +3025,11 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
         *fits = true;
         sv.nconst = -1;   // not known on the host
     } else {
-        TD_HIP(hipMemcpyAsync(c.pinned, ctl, 8 * sizeof(int), hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipMemcpyAsync(c.pinned, ctl, CTL_ALL * sizeof(int), hipMemcpyDeviceToHost, c.stream));
         TD_HIP(hipStreamSynchronize(c.stream));
         *fits = (((int *)c.pinned)[CTL_FLAG] == 0);
         sv.nconst = ((int *)c.pinned)[CTL_NCONST];
+        sv.range_seen = (int64_t)(((const unsigned long long *)((int *)c.pinned + CTL_RSEEN))[0]);   // exact: the largest row range of the pass
         if (!*fits) c.stats[6] = (int64_t)(((const unsigned long long *)((int *)c.pinned + CTL_RANGE))[0]);
     }
     if (*fits) {
@@ -3717,10 +3728,14 @@ restart:
             // 1-byte attempt: state init + the shape probe ride in front of the compress pass, which writes round 0's bids
             sv.want_bid0 = spec && !g_solver_eps;
             sv.probe = (spec && orient == 0 && g_shape && n >= 64 && n <= g_shape_max_n && !g_solver_eps) ? sv.d_cost : nullptr;
+            sv.range_seen = -1;
             rc = sv_compress(sv, bpc, &fits, spec);
             sv.want_bid0 = false;
             sv.probe = nullptr;
             if (rc) return rc;
+            // a width that fits after a mere lower bound of the range (the line probe's "row 0 is too wide for one byte"):
+            // the warm start's schedule and the "is it wide" test need the measured range
+            if (!spec && fits && sv.range_seen > known_range) known_range = sv.range_seen;
         }
         if (line_pending) {
             line_pending = false;
@@ -3875,7 +3890,7 @@ restart:
         // Wide, tie-free rows (no constant rows, few rows tied at their minimum) that the eps = 0
         // rounds leave with many free rows.  One small read-back; only non-speculative attempts
         // (u16 / u32 rows), which have synchronised for the width flag already.
-        bool wide = false;
+        bool wide = false, hard16 = false;
         if (g_warm && !g_solver_eps && !spec && bpc != 1 && sv.nconst == 0 && known_range >= g_warm_min_range) {
             k_freelist<<<1, 1024, 0, c.stream>>>(n, (const int *)sv.r2c.p, (int *)sv.list.p, (int *)sv.misc.p);
             TD_HIP(hipMemcpyAsync(c.pinned, sv.misc.p, CTL_ALL * sizeof(int), hipMemcpyDeviceToHost, c.stream));
@@ -3883,8 +3898,9 @@ restart:
             const int nfree_now = ((int *)c.pinned)[CTL_NFREE], tied0 = ((int *)c.pinned)[CTL_TIED];
             wide = !(nfree_now < std::max(g_warm_minfree, n / 64) || (long long)tied0 * 16 * g_warm_tie_div > n);   // tied0 counts every 16th row
             c.stats[2] = nfree_now;
+            hard16 = bpc == 2 && g_u16_redo_free > 0 && nfree_now >= g_u16_redo_free;
         }
-        if (wide && bpc == 2 && g_wide_u16_n && n >= g_wide_u16_n && g_narrow_price && !np_failed && known_range >= 0 &&
+        if ((wide || hard16) && bpc == 2 && g_wide_u16_n && n >= g_wide_u16_n && g_narrow_price && !np_failed && known_range >= 0 &&
             known_range <= NP_RANGE) {
             // A hard instance (the finisher will dominate) in 2-byte cells: the cooperative finisher k_sapx needs
             // n / E >= 8 * 256 chunks and the 2-byte kernels carry 64-bit prices.  Redo it as 4-byte cells with
