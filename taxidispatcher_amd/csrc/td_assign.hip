@@ -173,7 +173,7 @@ int g_sap8 = 1;             // TD_SAP8          lean u8 finisher
 int g_psap8_batches = 1;    // TD_PSAP8         speculative batches of the lean u8 search
 int g_psap8_grid = 64;      // TD_PSAP8_GRID    searches per such batch
 int g_warm_tie_div = 2;     // TD_WARM_TIE_DIV  no warm start when more than n / this rows are tied at their minimum
-int g_u16_redo_free = 0;     // TD_U16_REDO_FREE 2-byte rows that leave at least this many free rows after the eps = 0 rounds are redone as 4-byte cells (forest finisher) even when too many rows are tied for the warm start (0: off)
+int g_u16_redo_free = 64;    // TD_U16_REDO_FREE 2-byte rows that leave at least this many free rows after the eps = 0 rounds are redone as 4-byte cells (forest finisher) even when too many rows are tied for the warm start (0: off); uniform -5000..4999 at n = 16 384 (80 % of the rows tied at their minimum): 503 -> 35 ms
 int g_wide_u16_n = 2048;    // TD_WIDE_U16_N    wide, tie-free 2-byte rows of n >= this are redone as 4-byte cells with 32-bit prices (0: never); 4096 until the forest finisher took n >= 2048 (2-D Manhattan n = 2500 / 3500: 31 -> 21 ms, 46 -> 21 ms; uniform 0..40 000 n = 3000: 6.6 -> 7.1 ms)
 bool g_line = true;         // TD_LINE          0: skip the line-metric recogniser (td_line.hip), always run the general solver
 int g_line_min_n = 2;       // TD_LINE_MIN_N    smallest n the recogniser is tried on
