@@ -1151,12 +1151,14 @@ __global__ __launch_bounds__(256) void k_compress_tr(int n, int npad, const int3
 
 // The same pass for 1-byte cells with an escape (u8e): every cell is `esc_raw` (the fill value, code 254) or lies in
 // base .. base + 253, else CTL_FLAG is raised and the host redoes the pass with 4-byte cells.  A workgroup takes 64 of
-// the caller's columns x 1024 rows: the codes are staged transposed in LDS (row pitch 1028 bytes = 257 dwords: the 64
-// lanes of a wave hit 64 different banks), then every transposed row leaves as ONE contiguous KiB.
-constexpr int TR8_ROWS = 1024, TR8_LP = TR8_ROWS + 4;
+// the caller's columns x TR8_ROWS rows (512): the codes are staged transposed in LDS (row pitch TR8_ROWS + 4 bytes, an odd
+// number of dwords: the 64 lanes of a wave hit 64 different banks), then every transposed row leaves as one contiguous piece.
+template <int TR8_ROWS>
 __global__ __launch_bounds__(256) void k_compress_tr8(int n, int npad, const int32_t *__restrict__ in, uint8_t *__restrict__ out, int base,
                                                       int esc_raw, int *__restrict__ colmin, int *__restrict__ colmax, int *__restrict__ ctl)
 {
+    constexpr int TR8_LP = TR8_ROWS + 4;
+    static_assert(TR8_ROWS % 256 == 0, "a transposed row leaves as TR8_ROWS / 256 dwords per lane");
     extern __shared__ __attribute__((aligned(16))) unsigned char tb[];   // [64][TR8_LP]
     __shared__ int s_mn[64], s_mx[64];
     const int bx = blockIdx.x * 64, ry0 = blockIdx.y * TR8_ROWS;
@@ -1230,13 +1232,13 @@ __global__ __launch_bounds__(256) void k_compress_tr8(int n, int npad, const int
             atomicMax(&s_mx[4 * cg + x], mx[x]);
         }
     __syncthreads();
-    // wave wv writes the transposed rows wv * 16 .. + 15: lane l holds the dwords l, l + 64, l + 128, l + 192 of the row
+    // wave wv writes the transposed rows wv * 16 .. + 15: lane l holds the dwords l, l + 64, .. of the row
     for (int k = 0; k < 16; k++) {
         const int rr = wv * 16 + k, jj = bx + rr;
         if (jj >= n) break;
         const uint32_t *src = reinterpret_cast<const uint32_t *>(tb + (size_t)rr * TR8_LP);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < TR8_ROWS / 256; q++) {
             const int dw = lane + 64 * q, b = ry0 + 4 * dw;
             if (b < npad) *reinterpret_cast<uint32_t *>(out + (size_t)jj * npad + b) = src[dw];
         }
@@ -3067,10 +3069,18 @@ int sv_compress_fused(Solver &sv, bool *fits, int64_t *range, bool cells8 = fals
         k_fill_i32<<<(n + 255) / 256, 256, 0, c.stream>>>(colmin, n, INT_MAX);
         k_fill_i32<<<(n + 255) / 256, 256, 0, c.stream>>>(colmax, n, INT_MIN);
         if (cells8) {
-            const size_t shm = (size_t)64 * TR8_LP;
-            (void)hipFuncSetAttribute((const void *)k_compress_tr8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-            k_compress_tr8<<<dim3((n + 63) / 64, (n + TR8_ROWS - 1) / TR8_ROWS), 256, shm, c.stream>>>(n, npad, sv.d_cost, (uint8_t *)sv.cc.p, 0, esc_raw,
-                                                                                                      colmin, colmax, ctl);
+            static const int tr8_rows = getenv("TD_TR8_ROWS") ? atoi(getenv("TD_TR8_ROWS")) : 512;   // rows per tile: 512 = 33 KB of LDS, 4 workgroups per CU (g3 N = 16 384: compress 0.33 ms; 1024 rows, 2 per CU: 0.35 - 0.38; 256: 0.36)
+#define TD_TR8(R)                                                                                                                          \
+    do {                                                                                                                                   \
+        const size_t shm = (size_t)64 * (R + 4);                                                                                           \
+        (void)hipFuncSetAttribute((const void *)k_compress_tr8<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                  \
+        k_compress_tr8<R><<<dim3((n + 63) / 64, (n + R - 1) / R), 256, shm, c.stream>>>(n, npad, sv.d_cost, (uint8_t *)sv.cc.p, 0, esc_raw, \
+                                                                                       colmin, colmax, ctl);                              \
+    } while (0)
+            if (tr8_rows == 256) TD_TR8(256);
+            else if (tr8_rows == 512) TD_TR8(512);
+            else TD_TR8(1024);
+#undef TD_TR8
         } else if (n > 4096)   // tall workgroups: fewer atomics per column; small models need the workgroups instead
             k_compress_tr<8><<<dim3((n + 63) / 64, (n + 511) / 512), 256, 0, c.stream>>>(n, npad, sv.d_cost, (uint32_t *)sv.cc.p, 0, colmin, colmax, ctl);
         else
