@@ -273,6 +273,10 @@ class HipShard:
             _ffi.check(self.lib.td_synchronize())   # the exchange runs on torch's stream
         return int(off.value), int(ln.value)
 
+    def line_plausible(self, ws):
+        """after phase 0's exchange: did the anchors' owner find the first two rows compatible with a line metric"""
+        return int(ws[4].item()) != 0    # ctl word LC_PLAUS
+
     def line_result(self, ws):
         """(accepted, total, local row_to_col) after the last exchange"""
         r = np.empty(self.nrows, np.int32)
@@ -359,6 +363,8 @@ def line_sharded(shards, dist):
             sg.copy_(red)
         if len(segs) > 1:
             _fence(red)
+        if phase == 0 and hasattr(shards[0], "line_plausible") and not shards[0].line_plausible(wss[0]):
+            return None   # refused after ONE exchange (every rank reads the same summed word)
     out = [sh.line_result(ws) for sh, ws in zip(shards, wss)]
     if not all(acc for acc, _, _ in out):
         return None

@@ -186,7 +186,15 @@ class ModelShard:
                 i2 = int(np.argmax(e))
                 k1 = c[0, 0] ** 2 - c[0, q] ** 2
                 k2 = c[i2, 0] ** 2 - c[i2, q] ** 2
-                w[0:4] = [q, i2, int(k2 < k1), int(d[q] > 0 and e[i2] > 0)]
+                ok = bool(d[q] > 0 and e[i2] > 0)
+                if ok and self.nrows >= 2:   # the probe's first test on rows 0 and 1 (k_lsh_anchor)
+                    m = min(n, 1024)
+                    x, y = c[0, :m], c[1, :m]
+
+                    def span_ok(D):
+                        return bool(((x + y == D) | (np.abs(x - y) == D)).all())
+                    ok = span_ok(np.abs(x - y).max()) or span_ok((x + y).min())
+                w[0:4] = [q, i2, int(k2 < k1), int(ok)]
                 w[A:A + n] = c[0]
                 w[A + n:A + 2 * n] = c[i2]
             return 0, A + 2 * n
@@ -225,6 +233,9 @@ class ModelShard:
             w[FAIL] = int(bad)
             return FAIL, 1
         raise ValueError(phase)
+
+    def line_plausible(self, ws):
+        return int(ws.numpy()[3]) != 0
 
     def line_result(self, ws):
         n = self.n
