@@ -490,3 +490,53 @@ def test_fused_round0_in_shards_is_bit_identical(td, kind):
     if kind != "padded":    # (td_assign may solve a padded model transposed: another optimum among the ties)
         assert np.array_equal(ref, a[0])
     assert sorted(a[0].tolist()) == list(range(n))
+
+
+def _fused_worker(rank, world, port, n, seed, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import taxidispatcher_amd as td
+    from taxidispatcher_amd import _ffi, sharded
+    td.init(0)
+    row0, nrows, rps = sharded.shard_bounds(n, world, rank)
+    rows = torch.empty((nrows, n), dtype=torch.int32, device="cuda")
+    _ffi.check(_ffi.lib().td_gen_uniform(n, seed, 10, 40, row0, nrows, rows.data_ptr()))
+    sh = sharded.HipShard(n, row0, nrows, rows)
+    try:
+        r2c, total, dual = sharded.solve_sharded(sh, dist, want_dual=True)
+        path = sharded.solve_sharded.last_path
+    finally:
+        sh.close()
+    q.put((rank, np.asarray(r2c).tolist(), int(total), int(dual), path))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_wide_shards_fused_round0(td):
+    """two processes, shards wide enough for round 0 out of the compress pass (n = 12 288: k_compress_reg<.., BID0> through
+    solve_sharded's own sequence, the refused line attempt in front of it): the result is td_assign's, bit for bit"""
+    import torch
+    from taxidispatcher_amd import _ffi
+    n, seed = 12288, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fused_worker, args=(r, 2, port, n, seed, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = _collect(q, procs, 2)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    full = torch.empty((n, n), dtype=torch.int32, device="cuda")
+    _ffi.check(_ffi.lib().td_gen_uniform(n, seed, 10, 40, 0, n, full.data_ptr()))
+    ref, ref_total, ref_dual = td.assign(full, want_dual=True)
+    assert outs[0][2] == outs[1][2] == ref_total == ref_dual == outs[0][3] == outs[1][3]
+    assert outs[0][4] == outs[1][4] == "auction"
+    assert np.array_equal(np.array(outs[0][1] + outs[1][1]), ref)
