@@ -739,6 +739,23 @@ __global__ __launch_bounds__(1024) void k_lsh_anchor(int n, int nrows, const int
 {
     __shared__ ArgMax sh[16];
     const int t = threadIdx.x, T = blockDim.x;
+    if (nrows >= 2) {
+        // FIRST the probe's first test (k_line_probe step 0), so that a matrix that is no line metric costs a few loads and
+        // every rank ONE exchange: the first 1024 cells of rows 0 and 1 must agree on one distance |a_0 - a_1| (inside the
+        // two rows' span the distances add up to it, outside they differ by it)
+        const int m = n < 1024 ? n : 1024;
+        long long x = 0, y = 0;
+        ArgMax da = {-1, 0}, db = {LLONG_MIN, 0};
+        if (t < m) {
+            x = c[t], y = c[(size_t)n + t];
+            da.v = labs64(x - y), da.i = t;
+            db.v = -(x + y), db.i = t;
+        }
+        const long long Da = block_argmax(da, sh).v, Db = -block_argmax(db, sh).v;
+        const int bad_a = __syncthreads_or(t < m && !span_ok(x, y, Da));
+        const int bad_b = __syncthreads_or(t < m && !span_ok(x, y, Db));
+        if (bad_a && bad_b) return;   // ctl stays zero: LC_PLAUS = 0 (the workspace was cleared in front of this kernel)
+    }
     const long long c00 = c[0];
     ArgMax best = {-1, 0};
     for (int j = t; j < n; j += T) {
@@ -756,24 +773,7 @@ __global__ __launch_bounds__(1024) void k_lsh_anchor(int n, int nrows, const int
     }
     b2 = block_argmax(b2, sh);
     const int i2 = b2.i;
-    bool ok = okq && b2.v > 0;
-    if (ok && nrows >= 2) {
-        // the probe's first test (k_line_probe step 0), so that a matrix that is no line metric costs every rank ONE
-        // exchange: the first 1024 cells of rows 0 and 1 must agree on one distance |a_0 - a_1| (inside the two rows' span
-        // the distances add up to it, outside they differ by it)
-        const int m = n < 1024 ? n : 1024;
-        long long x = 0, y = 0;
-        ArgMax da = {-1, 0}, db = {LLONG_MIN, 0};
-        if (t < m) {
-            x = c[t], y = c[(size_t)n + t];
-            da.v = labs64(x - y), da.i = t;
-            db.v = -(x + y), db.i = t;
-        }
-        const long long Da = block_argmax(da, sh).v, Db = -block_argmax(db, sh).v;
-        const int bad_a = __syncthreads_or(t < m && !span_ok(x, y, Da));
-        const int bad_b = __syncthreads_or(t < m && !span_ok(x, y, Db));
-        ok = !(bad_a && bad_b);
-    }
+    const bool ok = okq && b2.v > 0;
     for (int j = t; j < n; j += T) {
         anch[j] = c[j];
         anch[N2 + j] = c[(size_t)i2 * n + j];
