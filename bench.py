@@ -119,12 +119,21 @@ class Workload:
             self.dem_from = torch.from_numpy(rng.integers(0, S, nd).astype(np.int32)).cuda()
             self.expected = None
             self.args = (10, 250000)
+        elif kind == "wide":   # uniform 0..10^6: tie-free 4-byte rows (VERDICT r2 item 1's second family); the matrix is made once
+            self.cost.copy_(torch.from_numpy(rng.integers(0, 10**6, (n, n)).astype(np.int32)))
+            self.expected = None
+        elif kind == "geo2":   # 2-D city grid, Manhattan distance (not in the reference, whose table is a line)
+            ax, ay, bx, by = (torch.from_numpy(rng.integers(0, 4000, n).astype(np.int32)).cuda() for _ in range(4))
+            self.cost.copy_((ax[:, None] - bx[None, :]).abs() + (ay[:, None] - by[None, :]).abs())
+            self.expected = None
         else:
             self.expected = 10 * n if n >= 1000 else None
 
     def build(self):
         if self.kind == "g1":
             self.ffi.check(self.lib.td_gen_uniform(self.n, self.seed, 10, 40, 0, self.n, self.cost.data_ptr()))
+        elif self.kind in ("wide", "geo2"):
+            pass   # resident matrix: the step is the solve alone
         else:
             thr, fill = self.args
             self.ffi.check(self.lib.td_cost_build(self.cab_to.data_ptr(), None, int(self.cab_to.numel()),
@@ -611,7 +620,8 @@ def main():
         # g2 twice: the default path (its |a-b| matrix is recognised as a line metric: sorted matching + certificate
         # pass, td_line.hip) and the general solver alone on the same instance (td_set_line_metric(0))
         for name, kind, en, reps in (("tick_1300x900", "tick", 0, 10), ("g3_n16384", "g3", 16384, 5), ("g2_n16384", "g2", 16384, 10),
-                                     ("g2_two_cabs_short_n16384", "g2u", 16384, 10), ("g2_n16384_general_solver", "g2", 16384, 2)):
+                                     ("g2_two_cabs_short_n16384", "g2u", 16384, 10), ("g2_n16384_general_solver", "g2", 16384, 2),
+                                     ("uniform_0_1e6_n16384_solve_only", "wide", 16384, 3), ("manhattan_2d_n16384_solve_only", "geo2", 16384, 2)):
             try:
                 td.set_line_metric(not name.endswith("general_solver"))
                 w2 = TickWorkload(1, td) if kind == "tick" else Workload(kind, en, 1, torch, td, ffi)
