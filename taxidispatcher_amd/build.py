@@ -28,15 +28,48 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
-           "-DTD_BUILDING=1", "-DTD_NT=%s" % os.environ.get("TD_NT", "2"),
-           "-DTD_SX_G=%s" % os.environ.get("TD_SX_G", "8"), "-DTD_SX_NG=%s" % os.environ.get("TD_SX_NG", "2"), "-DTD_SX_TX=%s" % os.environ.get("TD_SX_TX", "128"), "-o", LIB] + srcs
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden",
+             "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
+             "-DTD_BUILDING=1", "-DTD_NT=%s" % os.environ.get("TD_NT", "2"),
+             "-DTD_SX_G=%s" % os.environ.get("TD_SX_G", "8"), "-DTD_SX_NG=%s" % os.environ.get("TD_SX_NG", "2"),
+             "-DTD_SX_TX=%s" % os.environ.get("TD_SX_TX", "128")]
+    # one object per source, compiled side by side (no device symbol crosses a file), then one link; an object is
+    # rebuilt only when its source, a header or the flags changed
+    objdir = os.path.join(HERE, "csrc", "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    stamp = " ".join(flags)
+    hdr_t = max(os.path.getmtime(f) for f in HDR if os.path.exists(f))
+    jobs, objs = [], []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        fl = o + ".flags"
+        fresh = (not force and os.path.exists(o) and os.path.exists(fl) and open(fl).read() == stamp
+                 and os.path.getmtime(o) > max(os.path.getmtime(s), hdr_t))
+        if fresh:
+            continue
+        cmd = [hipcc] + flags + ["-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        jobs.append((s, o, fl, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    errs = []
+    for s, o, fl, pr in jobs:
+        out = pr.communicate()[0]
+        if pr.returncode != 0:
+            errs.append(out)
+            if os.path.exists(o):
+                os.remove(o)
+        else:
+            with open(fl, "w") as f:
+                f.write(stamp)
+    if errs:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(errs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
     return LIB
 
 
