@@ -267,6 +267,31 @@ TD_API int td_shard_total(td_shard *s, int64_t *partial_total, int64_t *partial_
 TD_API int td_shard_const_rows(td_shard *s, int32_t *mask_full, int set);
 TD_API int td_shard_options(td_shard *s, int flags);
 TD_API int td_shard_row_to_col(td_shard *s, int32_t *r2c_local);
+/* BLOCK-LOCAL START of the sharded solve (csrc/td_blocks.h; what SURVEY 8e's "one exchange per round" costs at
+ * N = 65 536 over 8 GPUs is the exchanges, not the rounds).  With td_shard_options(flags = 3) the 1-byte compress
+ * pass of a shard that owns whole diagonal blocks (n / 8 rows x the same columns) writes, for every row, a bid for
+ * the first ZERO cell of the row's own column slice; td_shard_phase_a then runs a few bidding rounds and a two-hop
+ * augmentation pass on the zero cells of those blocks — no price moves, every pair is tight, nothing is exchanged.
+ * The ranks then meet ONCE: td_shard_state_export writes this rank's segment (td_shard_state_words int32 words of
+ * device memory: fits / ran / free rows left / constant rows / range, the owners of its column slice, the
+ * constant-row flags of its rows), the caller all-gathers the segments in rank order, td_shard_state_import fills in
+ * the other slices (owners, owned bits, the replicated constant-row mask of td_shard_const_rows) and returns
+ * summary[0..4] = {all ranks fit, all ran phase A, free rows left in total, constant rows, largest row range}.
+ * The ordinary rounds (td_shard_bid / _apply / _rounds) and td_shard_finish take what is still free; when
+ * summary[2] == 0 the solve is complete.  td_assign starts the same way for n >= 12 288 (td_set_blocks),
+ * so a sharded run and td_assign with the same block count stay bit-identical. */
+TD_API int td_shard_blocks_pending(td_shard *s);
+TD_API int td_shard_phase_a(td_shard *s);
+TD_API int td_shard_state_words(td_shard *s, int rows_per_shard);
+TD_API int td_shard_state_export(td_shard *s, int rows_per_shard, int fits, int32_t *seg /* device */);
+TD_API int td_shard_state_import(td_shard *s, int world, int rank, int rows_per_shard, const int32_t *all /* device */,
+                                 int64_t *summary5 /* host */);
+/* summary[2] == 0 with constant rows in the model: every rank places them itself from the replicated owner[] and mask
+ * (k-th constant row <- k-th column nobody owns, what td_shard_finish does on its rank) — no finisher, no exchange */
+TD_API int td_shard_place_const(td_shard *s);
+/* diagonal blocks td_assign starts in: 0 = never, > 0 = that many (n must be a multiple of 16 * blocks, n >= 12 288),
+ * -1 = by size (8 from n = 12 288 on, where the 1-byte compress pass can write the bids).  Returns the previous setting. */
+TD_API int td_set_blocks(int blocks);
 /* The sorted matching of td_assign's line-metric path (cost = |a_i - b_j|, perf.jl's G2 family) over ROW SHARDS.
  * Replaces the same call as td_assign (simulator.py:199 / munkres.c solve / greedy_opt.py:95), for matrices one
  * GPU cannot hold.  `ws` is td_line_shard_ws_words(n) 64-bit words of device memory owned by the caller.  Every

@@ -81,6 +81,14 @@ SIGNATURES = {
     "td_shard_row_to_col": (ctypes.c_int, [ctypes.c_void_p, c_i32p]),
     "td_shard_const_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "td_shard_options": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "td_shard_blocks_pending": (ctypes.c_int, [ctypes.c_void_p]),
+    "td_shard_phase_a": (ctypes.c_int, [ctypes.c_void_p]),
+    "td_shard_state_words": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "td_shard_state_export": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "td_shard_state_import": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                             ctypes.POINTER(ctypes.c_int64)]),
+    "td_shard_place_const": (ctypes.c_int, [ctypes.c_void_p]),
+    "td_set_blocks": (ctypes.c_int, [ctypes.c_int]),
     "td_line_shard_ws_words": (ctypes.c_int64, [ctypes.c_int]),
     "td_line_shard_phase": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),

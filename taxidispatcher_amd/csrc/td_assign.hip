@@ -157,6 +157,8 @@ enum {
 };
 
 constexpr int ROW_BITS = 20;
+constexpr int HOP_FMAX = 128;   // td_blocks.h: free rows / columns of a block the two-hop pass looks at
+constexpr int HOP_BMAX = 16;    // td_blocks.h: blocks per shard
 
 // tunables (env TD_MAX_ROUNDS / TD_TIE_EVICT / TD_LDS_ROUNDS, read once at td_assign)
 // defaults are the measured best on MI355X (tools/gpu_sweep.py); every one has an env override
@@ -207,6 +209,13 @@ int g_forest = 1;           // TD_FOREST        cooperative incremental shortest
 int g_forest_min_n = 2048;  // TD_FOREST_MIN_N  smallest n it is used for
 long long g_forest_w0 = 16; // TD_FOREST_W0     first label window
 long long g_forest_wx = 16; // TD_FOREST_WX     how far above the smallest free-column label a window may reach
+int g_blocks = -1;          // TD_BLOCKS        block-local start of the 1-byte attempt (td_blocks.h): diagonal blocks of the matrix; 0: off, -1: by size (td_assign: off below TD_BLOCKS_MIN_N)
+int g_blocks_min_n = 12288; // TD_BLOCKS_MIN_N  smallest n td_assign starts block-locally by itself (perf.jl solve, n = 12 288 / 16 384 / 32 768 / 65 536: 0.61 / 0.76 / 2.26 / 7.5 -> 0.41 / 0.52 / 1.69 / 6.2 ms)
+int g_zs_rounds = 4;        // TD_ZS_ROUNDS     local bidding rounds of phase A after round 0
+int g_hop_passes = 2;       // TD_HOP_PASSES    two-hop passes at the end of phase A (the second one takes the rows the first pass's greedy left: 4 of 183 at n = 16 384)
+int g_hop_max_rows = HOP_FMAX;   // TD_HOP_MAX_ROWS  a block with more free rows than this is left to the rounds
+int g_hop_global = 1;       // TD_HOP_GLOBAL    td_assign: one two-hop pass over the whole matrix after phase A
+int g_zs_global_rounds = 6; // TD_ZS_GLOBAL_ROUNDS  td_assign: bidding rounds launched for what the block-local start left
 int g_solver_eps = 0;       // TD_SOLVER=eps    literal eps-scaling auction (comparison mode)
 int g_eps_theta = 8;        // TD_EPS_THETA
 long long g_eps0_mult = 4;  // TD_EPS0_MULT     eps0 = (n+1) * mult ; 0 = start at eps = 1
@@ -265,6 +274,13 @@ void read_tunables()
     if (const char *e = getenv("TD_LINE")) g_line = atoi(e) != 0;
     if (const char *e = getenv("TD_LINE_MIN_N")) g_line_min_n = std::max(2, atoi(e));
     if (const char *e = getenv("TD_PSAP8_GRID")) g_psap8_grid = std::max(1, std::min(192, atoi(e)));
+    if (const char *e = getenv("TD_BLOCKS")) g_blocks = std::max(-1, std::min(HOP_BMAX, atoi(e)));
+    if (const char *e = getenv("TD_BLOCKS_MIN_N")) g_blocks_min_n = std::max(0, atoi(e));
+    if (const char *e = getenv("TD_ZS_ROUNDS")) g_zs_rounds = std::max(0, std::min(32, atoi(e)));
+    if (const char *e = getenv("TD_HOP_PASSES")) g_hop_passes = std::max(0, std::min(8, atoi(e)));
+    if (const char *e = getenv("TD_HOP_MAX_ROWS")) g_hop_max_rows = std::max(1, atoi(e));
+    if (const char *e = getenv("TD_HOP_GLOBAL")) g_hop_global = atoi(e) != 0;
+    if (const char *e = getenv("TD_ZS_GLOBAL_ROUNDS")) g_zs_global_rounds = std::max(1, std::min(48, atoi(e)));
 }
 
 // ---- unpack one 16-byte chunk into E cost values -----------------------------------
@@ -450,7 +466,9 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(
     int n, int nrows, int nchunks, const int32_t *__restrict__ cost, CT *__restrict__ cc, int32_t *__restrict__ rowmin, int *__restrict__ ctl,
     int *__restrict__ rconst, const long long *__restrict__ skip, unsigned long long *__restrict__ bid = nullptr, int row0 = 0,
     int *__restrict__ r2c = nullptr /* BID0: constant rows are deferred (-2) */,
-    int probe_tickets = 0 /* BID0: > 0 = take a ticket of the shape probe at the end */)
+    int probe_tickets = 0 /* BID0: > 0 = take a ticket of the shape probe at the end */,
+    int zs_rpb = 0 /* BID0: > 0 = block-local start (td_blocks.h): rows per diagonal block; a row bids for the first ZERO cell of
+                      its own column slice only, never raising a price */)
 {
     static_assert(!BID0 || sizeof(CT) == 1, "round 0 out of the compress pass: 1-byte cells");
     if (skip && *skip) return;
@@ -477,7 +495,7 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(
             }
             if (fp == INT_MAX) return;   // the row did not bid (deferred, or too wide for one byte)
             unsigned m2 = 255;
-            if (c0 == 1) {   // (wave-uniform, rare in rows this wide) a single cell at the minimum: second smallest = the smallest non-zero byte of the row just written
+            if (c0 == 1 && !zs_rpb) {   // (wave-uniform, rare in rows this wide) a single cell at the minimum: second smallest = the smallest non-zero byte of the row just written
                 // (agent-scope loads: the words were stored by the other waves of this workgroup before the barrier, their
                 // stores acknowledged by L2; the CU's L1 is not trusted to have seen them)
                 const uint32_t *rp = reinterpret_cast<const uint32_t *>(cc + (size_t)prev_row * pitch);
@@ -496,7 +514,12 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(
                 const int grow = row0 + prev_row;
                 const int t1 = fp / E;
                 int ch = t1 + prev_rot;
-                if (ch >= nchunks) ch -= nchunks;
+                if (zs_rpb) {   // the rotation runs inside the row's column slice
+                    const int zcpb = zs_rpb / E;
+                    if (ch >= zcpb) ch -= zcpb;
+                    ch += (grow / zs_rpb) * zcpb;
+                } else if (ch >= nchunks)
+                    ch -= nchunks;
                 const int j1 = ch * E + (fp - t1 * E);
                 const unsigned long long inc = (c0 >= 2 || m2 == 255) ? 0ull : (unsigned long long)m2;
                 if (inc == 0 && (grow & 15) == 0) atomicAdd(&ctl[CTL_TIED], 1);
@@ -559,10 +582,12 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(
         // BID0 (row-uniform): the narrow words are scanned for zero bytes (= cells at the row minimum) as they are stored
         const bool deferred = BID0 && r2c && mx == mn;
         const bool bids = BID0 && fits && !deferred;
-        int fp = INT_MAX, c0 = 0, rot = 0;
+        int fp = INT_MAX, c0 = 0, rot = 0, zc0 = 0;
+        const int zcpb = BID0 ? zs_rpb / E : 0;
         if constexpr (BID0) {
             const uint32_t hsh = ((uint32_t)(row0 + row) + 1u) * 0x9E3779B1u;   // k_bid's rotation, round 0
-            rot = (int)(((uint64_t)(hsh ^ (hsh >> 15)) * (uint64_t)nchunks) >> 32);
+            rot = (int)(((uint64_t)(hsh ^ (hsh >> 15)) * (uint64_t)(zs_rpb ? zcpb : nchunks)) >> 32);
+            if (zs_rpb) zc0 = ((row0 + row) / zs_rpb) * zcpb;
         }
         CT *dst = cc + (size_t)row * pitch;
 #pragma unroll
@@ -578,10 +603,11 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(
                         // 0x80 in every byte of `word` that is zero (exact: no borrow between bytes)
                         // (branch-free: a divergent branch here makes the compiler wait for every store before the next)
                         const uint32_t z = ~(((word & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | word | 0x7F7F7F7Fu);
-                        int t = (q >> 2) - rot;   // position of the word's chunk in the row's rotated order
-                        t += t < 0 ? nchunks : 0;
+                        int t = (q >> 2) - zc0 - rot;   // position of the word's chunk in the row's rotated order
+                        const bool in_slice = !zs_rpb || (unsigned)((q >> 2) - zc0) < (unsigned)zcpb;
+                        t += t < 0 ? (zs_rpb ? zcpb : nchunks) : 0;
                         const int cand = t * 16 + (q & 3) * 4 + (__builtin_ctz(z | 0x80000000u) >> 3);
-                        fp = min(fp, z ? cand : INT_MAX);
+                        fp = min(fp, (z && in_slice) ? cand : INT_MAX);
                         c0 += __builtin_popcount(z);
                     }
                 } else if constexpr (sizeof(CT) == 2) {
@@ -969,6 +995,8 @@ __global__ __launch_bounds__(1024) void k_freelist(int n, const int *__restrict_
     const int cnt = build_free_list(n, r2c, list);
     if (threadIdx.x == 0) ctl[CTL_NFREE] = cnt;
 }
+
+#include "td_blocks.h"
 
 // Constant rows (every cell equal: dummy rows of a padded rectangular model, cabs with no request
 // in range) cost the same in any column, so they sit out the bidding and the searches and take
@@ -2899,9 +2927,14 @@ struct td_shard {
     bool fused_t = false;      // cc holds the TRANSPOSED problem built straight from the caller's matrix (k_compress_tr): d_cost is not transposed
     bool fused8 = false;       // ... as 1-byte cells with the escape code (u8e, bpc code 6)
     const long long *skip = nullptr;  // device flag of a pending line-metric probe: non-zero makes the compress pass a no-op
+    // block-local start (td_blocks.h)
+    int zs_V = 0;              // diagonal blocks of the whole matrix the 1-byte attempt may start in (0: off)
+    bool zs_done = false;      // the compress pass wrote the zero-slice bids of phase A's round 0: sv_phase_a is due
+    bool state_ready = false;  // sharded solve: the state was initialised in front of the compress pass and phase A has run on it (td_shard_begin must not redo it)
+    Buf ob, esc, hop, hoptab;  // owned bytes per column, escape masks per row, HopCtl, the two-hop tables
     void free_all()
     {
-        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &rconst, &misc, &psrec, &tbuf, &xbuf, &fbuf, &cmask};
+        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &rconst, &misc, &psrec, &tbuf, &xbuf, &fbuf, &cmask, &ob, &esc, &hop, &hoptab};
         for (Buf *b : bs) {
             if (b->p) (void)hipFree(b->p);
             b->p = nullptr;
@@ -2954,6 +2987,8 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
     const bool vec = (n % 4 == 0) && (((uintptr_t)sv.d_cost & 15) == 0);
     const int grid = std::max(1, std::min(nrows, c.n_cu * 8));
     sv.bid0_done = false;
+    sv.state_ready = false;
+    sv.zs_done = false;
     if (nrows > 0) {
         const int nq = n / 4;
         CT *cc = (CT *)sv.cc.p;
@@ -2963,6 +2998,12 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
         // pass itself marks the deferred constant rows), td_assign then skips sv_begin_t and round 0's k_bid
         const bool bid0 = sv.want_bid0 && g_bid0 && sizeof(CT) == 1 && g_creg && vec && nq >= 3072 && nq <= 1024 * 16;   // n >= 12 288 (n = 9000: 0.52 -> 0.56 ms, the pass has too few rows per CU to hide the scan)
         int tickets = 0;
+        // block-local start: whole diagonal blocks only, chunk-aligned column slices
+        int zs_rpb = 0;
+        if (bid0 && sv.zs_V > 0 && n % (sv.zs_V * E) == 0) {
+            const int rpb = n / sv.zs_V;
+            if (sv.row0 % rpb == 0 && nrows % rpb == 0 && nrows / rpb <= HOP_BMAX) zs_rpb = rpb;
+        }
         static const int gbm = getenv("TD_BID0_GRID") ? atoi(getenv("TD_BID0_GRID")) : 0;
         const int gb = std::max(1, std::min(nrows, c.n_cu * (gbm > 0 ? gbm : std::max(1, g_cgrid / 2))));   // 512-thread workgroups of the BID0 pass
         if (bid0) {
@@ -2993,10 +3034,11 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
                     static const int shape = getenv("TD_BID0_SHAPE") ? atoi(getenv("TD_BID0_SHAPE")) : 0;
                     if (shape == 1)
                         k_compress_reg<CT, 4, 1024, true><<<gb, 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
-                                                                                    sv.row0, defer_r2c, tickets);
+                                                                                    sv.row0, defer_r2c, tickets, zs_rpb);
                     else
                         k_compress_reg<CT, 8, 512, true><<<gb, 512, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
-                                                                                   sv.row0, defer_r2c, tickets);
+                                                                                   sv.row0, defer_r2c, tickets, zs_rpb);
+                    sv.zs_done = zs_rpb > 0;
                 }
             } else {
                 static const int cshape = getenv("TD_CREG_SHAPE") ? atoi(getenv("TD_CREG_SHAPE")) : 0;
@@ -3011,8 +3053,11 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
             const int g4 = std::max(1, std::min(nrows, c.n_cu * 2));
             if (bid0) {
                 if constexpr (sizeof(CT) == 1)
+                {
                     k_compress_reg<CT, 16, 1024, true><<<g4, 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
-                                                                                  sv.row0, defer_r2c, tickets);
+                                                                                  sv.row0, defer_r2c, tickets, zs_rpb);
+                    sv.zs_done = zs_rpb > 0;
+                }
             } else
                 k_compress_reg<CT, 16, 1024><<<g4, 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip);
         } else if (vec)
@@ -3109,6 +3154,77 @@ int sv_compress_fused(Solver &sv, bool *fits, int64_t *range, bool cells8 = fals
     return TD_OK;
 }
 
+// One two-hop pass (td_blocks.h) over `nb` blocks of rpb rows x ncols_blk columns starting at column col_lo.
+template <typename CT>
+int sv_hop_t(Solver &sv, int rpb, int ncols_blk, int col_lo, int nb, bool window_zero, uint8_t *ob)
+{
+    Ctx &c = ctx();
+    using PT = typename Tr<CT>::PT;
+    int rc;
+    if ((rc = ensure(sv.esc, sizeof(unsigned long long) * 2 * (size_t)std::max(sv.nrows, 1)))) return rc;
+    if ((rc = ensure(sv.hop, sizeof(HopCtl)))) return rc;
+    if ((rc = ensure(sv.hoptab, sizeof(int) * (size_t)nb * HOP_FMAX * HOP_FMAX))) return rc;
+    HopCtl *hc = (HopCtl *)sv.hop.p;
+    int *frl = (int *)sv.list.p, *fcl = (int *)sv.pred.p;   // free until the finisher
+    const int *ctl = (const int *)sv.misc.p;
+    k_hop_lists<<<nb, 1024, 0, c.stream>>>(rpb, ncols_blk, col_lo, (const int *)sv.r2c.p, (const int *)sv.owner.p, frl, fcl, hc, ctl);
+    k_hop_esc<CT><<<(sv.nrows + 3) / 4, 256, 0, c.stream>>>(sv.nrows, sv.nchunks, rpb, ncols_blk, col_lo, g_hop_max_rows, (const CT *)sv.cc.p,
+                                                            (const PT *)sv.price.p, (const int *)sv.r2c.p, fcl, hc,
+                                                            (unsigned long long *)sv.esc.p, ctl);
+    k_hop_table<CT><<<nb * HOP_FMAX, 256, 0, c.stream>>>(sv.n, sv.nrows, sv.row0, sv.nchunks, rpb, ncols_blk, col_lo, g_hop_max_rows,
+                                                         window_zero ? 1 : 0, (const CT *)sv.cc.p, (const PT *)sv.price.p,
+                                                         (const int *)sv.owner.p, frl, hc, (const unsigned long long *)sv.esc.p,
+                                                         (int *)sv.hoptab.p, ctl);
+    k_hop_match<PT><<<nb, HOP_FMAX, sizeof(uint32_t) * (size_t)((rpb + 31) / 32), c.stream>>>(
+        sv.nrows, sv.row0, rpb, ncols_blk, col_lo, g_hop_max_rows, (PT *)sv.price.p, (int *)sv.owner.p, (int *)sv.r2c.p, ob, frl, fcl, hc,
+        (const int *)sv.hoptab.p, (int *)sv.misc.p);
+    TD_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// Phase A of a 1-byte attempt whose compress pass wrote the zero-slice bids (sv.zs_done): everything local to this
+// shard's diagonal blocks, no price moves.  Leaves the ordinary state (owner / r2c / packed prices with the owned bit)
+// for the global rounds; the free rows it left are counted in HopCtl::left.
+int sv_phase_a(Solver &sv)
+{
+    Ctx &c = ctx();
+    const int n = sv.n, nrows = sv.nrows;
+    const int rpb = n / sv.zs_V, nb = nrows / rpb;
+    const int col_lo = (sv.row0 / rpb) * rpb, col_hi = col_lo + nb * rpb;
+    int rc;
+    if ((rc = ensure(sv.ob, (size_t)sv.npad + 64))) return rc;
+    TD_HIP(hipMemsetAsync(sv.ob.p, 0, (size_t)sv.npad, c.stream));
+    ProfScope ps(TD_K_BID);
+    int *ctl = (int *)sv.misc.p;
+    const int ga = (col_hi - col_lo + 255) / 256;
+    unsigned long long *bid = (unsigned long long *)sv.bid.p;
+    auto assign = [&]() {
+        k_zs_assign<<<ga, 256, 0, c.stream>>>(col_lo, col_hi, nrows, sv.row0, bid, (int32_t *)sv.price.p, (int *)sv.owner.p, (int *)sv.r2c.p,
+                                              (uint8_t *)sv.ob.p, ctl);
+    };
+    assign();   // round 0: the bids came out of the compress pass
+    for (int r = 1; r <= g_zs_rounds; r++) {
+        k_zs_bid<<<std::min(nrows, c.n_cu * 16), 256, 0, c.stream>>>(nrows, sv.row0, sv.nchunks, rpb, (const uint8_t *)sv.cc.p,
+                                                                     (const uint8_t *)sv.ob.p, (const int *)sv.r2c.p, bid, ctl, r, g_tie_evict);
+        assign();
+    }
+    TD_HIP(hipGetLastError());
+    for (int p = 0; p < g_hop_passes; p++)
+        if ((rc = sv_hop_t<uint8_t>(sv, rpb, rpb, col_lo, nb, true, (uint8_t *)sv.ob.p))) return rc;
+    if (getenv("TD_DEBUG") && g_hop_passes > 0) {
+        HopCtl h;
+        TD_HIP(hipMemcpyAsync(&h, sv.hop.p, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipStreamSynchronize(c.stream));
+        fprintf(stderr, "[td] phase A: %d blocks of %d rows, %d local rounds; free rows / columns per block before the last two-hop pass:", nb, rpb, g_zs_rounds);
+        for (int b = 0; b < nb; b++) fprintf(stderr, " %d/%d", h.nfr[b], h.nfc[b]);
+        fprintf(stderr, " | matched %d, left %d\n", h.matched, h.left);
+    }
+    sv.zs_done = false;
+    sv.bid0_done = false;   // the global rounds start with a round 0 of their own
+    sv.state_ready = true;
+    return TD_OK;
+}
+
 template <typename CT>
 int sv_begin_t(Solver &sv)
 {
@@ -3135,17 +3251,18 @@ int sv_bid_t(Solver &sv, int r, unsigned long long *keys)
     const int tie_evict = (r >= 1) ? g_tie_evict : 0;
     ProfScope ps(TD_K_BID);
     int *tied = (r == 0) ? (int *)sv.misc.p + CTL_TIED : nullptr;
-    if (can_lds && r < g_lds_rounds) {
+    const bool sparse = sv.state_ready;   // after the block-local start few rows are free: every round is a handful of row workgroups
+    if (can_lds && r < g_lds_rounds && !sparse) {
         if (lds_prices > 48 * 1024)
             (void)hipFuncSetAttribute((const void *)k_bid<CT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prices);
         const int grid = std::min((nrows + 15) / 16, c.n_cu * g_lds_grid);
         k_bid<CT, true><<<grid, 1024, lds_prices, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
                                                               (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict, 1, 0, tied);
-    } else if (r >= g_row_rounds) {
+    } else if (r >= g_row_rounds || sparse) {
         // one workgroup per row while a round still has hundreds of bidders (perf.jl: 9.5 us against 10.4 with the loop),
         // a grid-stride loop over the rows from round TD_ROW_LOOP on, where a handful is left and spawning 16 384
         // workgroups to see that their rows are assigned costs more than the round's work
-        k_bid_row<CT><<<(r < g_row_loop) ? nrows : std::min(nrows, c.n_cu * 8), 256, 0, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
+        k_bid_row<CT><<<(r < g_row_loop && !sparse) ? nrows : std::min(nrows, c.n_cu * 8), 256, 0, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
                                                    (const int *)sv.r2c.p, keys, (const int *)sv.misc.p, r, tie_evict);
     } else {
         k_bid<CT, false><<<(nrows + 3) / 4, 256, 0, c.stream>>>(n, nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p,
@@ -3731,12 +3848,14 @@ restart:
     compress_pass:
         if (sv.fused_t) {   // cc already holds the transposed problem (k_compress_tr); the same bytes serve both price widths
             sv.bid0_done = false;   // (a 1-byte attempt queued before the fused pass may have set it)
+            sv.zs_done = false;
             fits = true;
             sv.bpc = bpc;
             if (np_failed) k_fill_i32<<<1, 64, 0, c.stream>>>((int *)sv.misc.p + CTL_FLAG, 2, 0);   // the price-limit flag of the 32-bit attempt
         } else {
             // 1-byte attempt: state init + the shape probe ride in front of the compress pass, which writes round 0's bids
             sv.want_bid0 = spec && !g_solver_eps;
+            sv.zs_V = (sv.want_bid0 && orient == 0) ? (g_blocks >= 0 ? g_blocks : (n >= g_blocks_min_n ? 8 : 0)) : 0;
             sv.probe = (spec && orient == 0 && g_shape && n >= 64 && n <= g_shape_max_n && !g_solver_eps) ? sv.d_cost : nullptr;
             sv.range_seen = -1;
             rc = sv_compress(sv, bpc, &fits, spec);
@@ -3877,8 +3996,9 @@ restart:
             solved = true;
             break;
         }
+        int round_cap = max_rounds;
         auto rounds = [&](bool first) -> int {
-            for (int r = 0; r < max_rounds; r++) {
+            for (int r = 0; r < round_cap; r++) {
                 rc = TD_OK;
                 if (!(r == 0 && first && sv.bid0_done)) TD_DISPATCH(sv, sv_bid_t, sv, r, (unsigned long long *)sv.bid.p);
                 if (rc) return rc;
@@ -3896,7 +4016,24 @@ restart:
             g_warm_bits = keep;
             return rc;
         };
-        if ((rc = rounds(true))) return rc;
+        bool all_placed = false;
+        if (sv.zs_done) {
+            // block-local start (td_blocks.h): zero cells of the diagonal blocks, then one two-hop pass over the whole
+            // matrix for what the blocks left; one small read-back tells whether anything is left for the rounds and the
+            // finisher (on tie-heavy instances nothing is: ~30 launches that would all exit at once are not made)
+            if ((rc = sv_phase_a(sv))) return rc;
+            if (g_hop_global && (rc = sv_hop_t<uint8_t>(sv, n, n, 0, 1, false, nullptr))) return rc;
+            if (g_hop_passes > 0 || g_hop_global) {
+                int *pin = (int *)c.pinned;
+                TD_HIP(hipMemcpyAsync(pin, (char *)sv.hop.p + offsetof(HopCtl, left), sizeof(int), hipMemcpyDeviceToHost, c.stream));
+                TD_HIP(hipMemcpyAsync(pin + 1, (int *)sv.misc.p + CTL_FLAG, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+                TD_HIP(hipStreamSynchronize(c.stream));
+                all_placed = pin[0] == 0 && pin[1] == 0;
+                if (getenv("TD_DEBUG")) fprintf(stderr, "[td] after the block-local start: %d rows free, flag %d\n", pin[0], pin[1]);
+                round_cap = std::min(max_rounds, g_zs_global_rounds);
+            }
+        }
+        if (!all_placed && (rc = rounds(true))) return rc;
         // Wide, tie-free rows (no constant rows, few rows tied at their minimum) that the eps = 0
         // rounds leave with many free rows.  One small read-back; only non-speculative attempts
         // (u16 / u32 rows), which have synchronised for the width flag already.
@@ -3929,7 +4066,7 @@ restart:
         tab.rps = n;
         tab.count = 1;
         sv.placed = false;
-        TD_DISPATCH(sv, sv_finish_t, sv, tab, (int *)sv.r2c.p);
+        if (!all_placed) TD_DISPATCH(sv, sv_finish_t, sv, tab, (int *)sv.r2c.p);
         if (rc) return rc;
         if (sv.defer_const && !sv.placed) {
             ProfScope ps(TD_K_FINAL);
@@ -4034,6 +4171,14 @@ extern "C" int td_set_line_metric(int on)
     return was;
 }
 
+extern "C" int td_set_blocks(int blocks)
+{
+    read_tunables();
+    const int was = g_blocks;
+    g_blocks = std::max(-1, std::min(HOP_BMAX, blocks));
+    return was;
+}
+
 extern "C" void td_assign_release_workspace(void)
 {
     g_default.free_all();
@@ -4123,6 +4268,130 @@ int td_shard_options(td_shard *s, int flags)
     if (!s) return fail(TD_EINVAL, "null shard");
     s->want_bid0 = (flags & 1) != 0 && !g_solver_eps;
     if (s->want_bid0) s->defer_const = g_defer_const && !g_solver_eps;
+    // bit 1: block-local start (td_blocks.h) — the 1-byte compress pass writes zero-slice bids, td_shard_phase_a runs the
+    // local rounds and the two-hop pass, td_shard_state_export / _import carry the ONE exchange that follows
+    s->zs_V = ((flags & 3) == 3 && s->want_bid0) ? (g_blocks > 0 ? g_blocks : (g_blocks < 0 ? 8 : 0)) : 0;
+    return TD_OK;
+}
+
+// 1 when the last td_shard_compress wrote the zero-slice bids of the block-local start: td_shard_phase_a is due
+int td_shard_blocks_pending(td_shard *s) { return (s && s->zs_done) ? 1 : 0; }
+
+int td_shard_phase_a(td_shard *s)
+{
+    TD_REQUIRE_INIT();
+    if (!s) return fail(TD_EINVAL, "null shard");
+    if (!s->zs_done || s->bpc != 1) return fail(TD_EINVAL, "td_shard_phase_a: the compress pass did not prepare a block-local start");
+    return sv_phase_a(*s);
+}
+
+// The ONE exchange after phase A.  Every rank exports a segment of td_shard_state_words() int32 words (device memory):
+//   [0] 1 = this rank's rows fit one byte  [1] 1 = phase A ran here  [2] free rows phase A left  [3] constant rows
+//   [4..5] largest row range (int64)  [6..15] spare, then the owners of the rank's column slice (rows_per_shard words,
+//   global row ids, -1 free) and the constant-row flags of its rows (rows_per_shard words).
+// The caller all-gathers the segments (rank order) and hands the concatenation to td_shard_state_import, which fills in
+// the other ranks' owner slices, the owned bits of the packed prices and the replicated constant-row mask
+// (td_shard_const_rows' job), and returns summary[0..4] = {all fit, all ran phase A, free rows left in total,
+// constant rows in total, largest row range}.
+int td_shard_state_words(td_shard *s, int rows_per_shard) { return s ? 16 + 2 * rows_per_shard : 0; }
+}   // extern "C"
+
+namespace {
+__global__ void k_state_export(int nrows, int rps, int col_lo, int fits, int ran, const int *__restrict__ owner,
+                               const int *__restrict__ rconst, const HopCtl *__restrict__ hc, const int *__restrict__ ctl,
+                               int32_t *__restrict__ seg)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 16) {
+        int v = 0;
+        if (t == 0) v = fits && ctl[CTL_FLAG] == 0;
+        if (t == 1) v = ran;
+        if (t == 2) v = (ran && hc) ? hc->left : -1;
+        if (t == 3) v = ctl[CTL_NCONST];
+        if (t == 4) v = ctl[CTL_RSEEN];
+        if (t == 5) v = ctl[CTL_RSEEN + 1];
+        seg[t] = v;
+    }
+    if (t < rps) {
+        seg[16 + t] = (ran && t < nrows) ? owner[col_lo + t] : -1;
+        seg[16 + rps + t] = (t < nrows && rconst[t]) ? 1 : 0;
+    }
+}
+
+__global__ void k_state_import(int n, int world, int rps, int words, int own_rank, const int32_t *__restrict__ all,
+                               int *__restrict__ owner, int32_t *__restrict__ pk, int *__restrict__ cmask, long long *__restrict__ summary)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        long long fit = 1, ran = 1, left = 0, nconst = 0, range = 0;
+        for (int r = 0; r < world; r++) {
+            const int32_t *h = all + (size_t)r * words;
+            fit = fit && h[0];
+            ran = ran && h[1];
+            left += h[2] >= 0 ? h[2] : n;   // unknown (no two-hop pass counted them): assume rows are free
+            nconst += h[3];
+            const long long rg = (long long)(((unsigned long long)(uint32_t)h[5] << 32) | (uint32_t)h[4]);
+            range = rg > range ? rg : range;
+        }
+        summary[0] = fit;
+        summary[1] = ran;
+        summary[2] = left;
+        summary[3] = nconst;
+        summary[4] = range;
+    }
+    if (t < n) {
+        const int r = t / rps, k = t - r * rps;
+        const int32_t *seg = all + (size_t)r * words;
+        if (r != own_rank) {
+            const int o = seg[16 + k];
+            owner[t] = o;
+            pk[t] = (pk[t] & ~1) | (o >= 0 ? 1 : 0);
+        }
+        cmask[t] = seg[16 + rps + k];
+    }
+}
+}   // namespace
+
+extern "C" {
+int td_shard_state_export(td_shard *s, int rows_per_shard, int fits, int32_t *seg)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (!s || !seg || rows_per_shard < s->nrows) return fail(TD_EINVAL, "td_shard_state_export: bad arguments");
+    if (!is_device_ptr(seg)) return fail(TD_EINVAL, "td_shard_state_export: the segment must be device memory");
+    const bool ran = s->state_ready && s->bpc == 1 && s->zs_V > 0;
+    int col_lo = 0;
+    if (ran) col_lo = (s->row0 / (s->n / s->zs_V)) * (s->n / s->zs_V);
+    ProfScope ps(TD_K_ASSIGN);
+    k_state_export<<<(std::max(rows_per_shard, 16) + 255) / 256, 256, 0, c.stream>>>(
+        s->nrows, rows_per_shard, col_lo, fits ? 1 : 0, ran ? 1 : 0, (const int *)s->owner.p, (const int *)s->rconst.p,
+        ran ? (const HopCtl *)s->hop.p : nullptr, (const int *)s->misc.p, seg);
+    TD_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+int td_shard_state_import(td_shard *s, int world, int rank, int rows_per_shard, const int32_t *all, int64_t *summary5)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (!s || !all || !summary5 || world < 1 || rank < 0 || rank >= world) return fail(TD_EINVAL, "td_shard_state_import: bad arguments");
+    if (!is_device_ptr(all)) return fail(TD_EINVAL, "td_shard_state_import: the segments must be device memory");
+    if ((long long)rows_per_shard * world < s->n) return fail(TD_EINVAL, "td_shard_state_import: rows_per_shard * world < n");
+    int rc;
+    if ((rc = ensure(s->cmask, sizeof(int) * (size_t)(s->n + 16)))) return rc;
+    long long *sum_dev = (long long *)((char *)s->misc.p + 2048);   // clear of the control words (0..) and the totals (1024)
+    const int words = 16 + 2 * rows_per_shard;
+    {
+        ProfScope ps(TD_K_ASSIGN);
+        k_state_import<<<(s->n + 255) / 256, 256, 0, c.stream>>>(s->n, world, rows_per_shard, words, rank, all, (int *)s->owner.p,
+                                                            (int32_t *)s->price.p, (int *)s->cmask.p, sum_dev);
+    }
+    TD_HIP(hipGetLastError());
+    TD_HIP(hipMemcpyAsync(c.pinned, sum_dev, 5 * sizeof(long long), hipMemcpyDeviceToHost, c.stream));
+    TD_HIP(hipStreamSynchronize(c.stream));
+    for (int k = 0; k < 5; k++) summary5[k] = ((const long long *)c.pinned)[k];
+    s->have_cmask = true;
+    s->defer_const = g_defer_const && !g_solver_eps;
     return TD_OK;
 }
 
@@ -4144,7 +4413,7 @@ int td_shard_begin(td_shard *s, int64_t global_range)
     if ((double)(range + 1) * (double)(s->n + 1) >= 4.0e12)
         return fail(TD_ERANGE, "row cost range %lld with n=%d overflows the packed bid key (price < 2^43)", (long long)range, s->n);
     int rc = TD_OK;
-    if (!s->bid0_done) TD_DISPATCH(*s, sv_begin_t, *s);   // (else the compress pass has initialised the state in front of itself)
+    if (!s->bid0_done && !s->state_ready) TD_DISPATCH(*s, sv_begin_t, *s);   // (else the compress pass has initialised the state in front of itself)
     return rc;
 }
 
@@ -4330,6 +4599,30 @@ int td_shard_finish(td_shard *s, int world, const void *const *shard_ptrs, int r
     }
     TD_HIP(hipGetLastError());
     TD_HIP(hipStreamSynchronize(c.stream));
+    return TD_OK;
+}
+
+// Every row that bids has its column (td_shard_state_import's summary[2] == 0) but the model has deferred constant rows:
+// each rank gives them the columns nobody owns, k-th constant row <- k-th free column, from the REPLICATED owner[] and
+// constant-row mask — the same placement on every rank, no finisher, no exchange.
+int td_shard_place_const(td_shard *s)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (!s || !s->have_cmask) return fail(TD_EINVAL, "td_shard_place_const: no constant-row mask (td_shard_state_import / td_shard_const_rows first)");
+    const int n = s->n;
+    int rc;
+    if ((rc = ensure(s->r2c_full, sizeof(int) * (size_t)(n + 16)))) return rc;
+    int *full = (int *)s->r2c_full.p;
+    k_fill_i32<<<(n + 255) / 256, 256, 0, c.stream>>>(full, n, -1);
+    k_r2c_from_owner<<<(n + 255) / 256, 256, 0, c.stream>>>(n, n, 0, (const int *)s->owner.p, full);
+    k_mark_const<<<1, 1024, 0, c.stream>>>(n, (const int *)s->cmask.p, full, (int *)s->misc.p);
+    k_place_const<<<1, 1024, 0, c.stream>>>(n, full, (int *)s->owner.p, (int *)s->list.p, (int *)s->pred.p, (int *)s->misc.p);
+    if (s->nrows > 0) {
+        k_fill_i32<<<(s->nrows + 255) / 256, 256, 0, c.stream>>>((int *)s->r2c.p, s->nrows, -1);
+        k_r2c_from_owner<<<(n + 255) / 256, 256, 0, c.stream>>>(n, s->nrows, s->row0, (const int *)s->owner.p, (int *)s->r2c.p);
+    }
+    TD_HIP(hipGetLastError());
     return TD_OK;
 }
 

@@ -244,6 +244,35 @@ class HipShard:
         bids itself (td_shard_options)"""
         _ffi.check(self.lib.td_shard_options(self.h, 1 if on else 0))
 
+    # -- block-local start (csrc/td_blocks.h): phase A on the shard's own diagonal blocks, then ONE exchange
+    def blocks_start(self, on=True):
+        _ffi.check(self.lib.td_shard_options(self.h, 3 if on else 1))
+
+    def blocks_pending(self):
+        return bool(self.lib.td_shard_blocks_pending(self.h))
+
+    def phase_a(self):
+        _ffi.check(self.lib.td_shard_phase_a(self.h))
+
+    def state_segment(self, rps, fits):
+        """this rank's segment of the exchange after phase A (int32 device tensor)"""
+        seg = self.torch.empty(int(self.lib.td_shard_state_words(self.h, int(rps))), dtype=self.torch.int32, device=self.device)
+        if not self.shared_stream:
+            self.torch.cuda.current_stream().synchronize()
+        _ffi.check(self.lib.td_shard_state_export(self.h, int(rps), 1 if fits else 0, seg.data_ptr()))
+        if not self.shared_stream:
+            _ffi.check(self.lib.td_synchronize())   # the exchange runs on torch's stream
+        return seg
+
+    def place_const(self):
+        _ffi.check(self.lib.td_shard_place_const(self.h))
+
+    def state_import(self, world, rank, rps, allseg):
+        """the gathered segments -> the other slices' owners, the constant-row mask; returns the summary"""
+        out = (ctypes.c_int64 * 5)()
+        _ffi.check(self.lib.td_shard_state_import(self.h, int(world), int(rank), int(rps), allseg.data_ptr(), out))
+        return {"fit": bool(out[0]), "ran": bool(out[1]), "left": int(out[2]), "nconst": int(out[3]), "range": int(out[4])}
+
     # -- constant rows sit out the solve (td_shard_const_rows)
     def const_mask(self):
         """zeroed device mask of n ints with this shard's constant rows set (after compress); the caller sums it"""
@@ -337,6 +366,32 @@ def all_gather_equal(dist, t):
     return out
 
 
+def all_gather_cat(dist, t):
+    """all_gather of equally sized 1-D tensors -> one tensor, rank order"""
+    world = dist.get_world_size()
+    if _staged(dist, t):
+        c = t.cpu()
+        out = c.new_empty(world * c.numel())
+        dist.all_gather(list(out.chunk(world)), c)
+        return out.to(t.device)
+    out = t.new_empty(world * t.numel())
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out, t)
+    else:
+        dist.all_gather(list(out.chunk(world)), t)
+    _fence(out)
+    return out
+
+
+BLOCKS = 8   # diagonal blocks of the block-local start (a rank owns BLOCKS / world of them)
+
+
+def blocks_ok(n, world):
+    """can every rank start block-locally: whole blocks per rank, chunk-aligned column slices, rows wide enough for the
+    compress pass that writes the zero-slice bids (k_compress_reg<.., BID0>: n >= 12 288)"""
+    return BLOCKS % world == 0 and n % (16 * BLOCKS) == 0 and 12288 <= n <= 65536
+
+
 LINE_PHASES = 4
 
 
@@ -397,33 +452,63 @@ def _solve_sharded(shard, dist, rounds, want_dual, use_ipc):
         if got is not None:
             total, (r2c,) = got
             return (r2c, total, total) if want_dual else (r2c, total)
-    # 1. agree on the storage width (every rank must use the same one)
     defer = hasattr(shard, "const_mask") and os.environ.get("TD_DEFER_CONST", "1") != "0"
-    if hasattr(shard, "fused_round0"):
-        shard.fused_round0(defer)   # round 0 out of the compress pass needs the constant-row exchange below
-    for width in (1, 2, 4):
-        flag = shard.scalar_tensor([1 if shard.compress(width) else 0])
-        if world > 1:
-            all_reduce(dist, flag, MIN)
-        if int(flag[0].item()) == 1:
-            break
-    else:
-        raise _ffi.TdError("row cost range exceeds 2^32-2 on some rank")
-    # constant rows (dummy cabs of a padded model) sit out the rounds and the searches, as in td_assign: one SUM
-    # all-reduce of an n-int mask tells every rank (the finisher's above all) which rows they are
-    if defer:
-        mask = shard.const_mask()
-        if world > 1:
-            all_reduce(dist, mask, SUM)
-        shard.set_const_mask(mask)
-    # the packed-key range guard needs the largest row range of ANY rank (td_assign's TD_ERANGE rule)
-    grange = -1
-    if hasattr(shard, "range"):
-        rt = shard.scalar_tensor([shard.range()])
-        if world > 1:
-            all_reduce(dist, rt, MAX)
-        grange = int(rt[0].item())
-    shard.begin(grange)
+    # 1a. block-local start (csrc/td_blocks.h): the 1-byte attempt begins on every rank's own diagonal blocks — zero
+    #     cells only, no price moves, nothing exchanged — and the ranks then meet ONCE (an all-gather that carries the
+    #     width flag, the owners of each rank's column slice and its constant rows).  On tie-heavy instances
+    #     (perf.jl) nothing is left for the rounds.
+    widths = (1, 2, 4)
+    left = None
+    can_blocks = shard.blocks_ok(n, world) if hasattr(shard, "blocks_ok") else blocks_ok(n, world)
+    if defer and hasattr(shard, "phase_a") and os.environ.get("TD_SHARD_BLOCKS", "1") != "0" and can_blocks:
+        shard.blocks_start(True)
+        fits = shard.compress(1)
+        if fits and shard.blocks_pending():
+            shard.phase_a()
+        seg = shard.state_segment(rps, fits)
+        allseg = all_gather_cat(dist, seg) if (world > 1 or os.environ.get("TD_SHARD_FORCE_AR")) else seg
+        summ = shard.state_import(world, rank, rps, allseg)
+        if summ["fit"] and summ["ran"]:
+            left = summ["left"]
+            shard.begin(summ["range"])
+            solve_sharded.last_path = "blocks"
+        else:
+            shard.blocks_start(False)
+            widths = (1, 2, 4) if summ["fit"] else (2, 4)
+    if left is None:
+        # 1b. agree on the storage width (every rank must use the same one)
+        if hasattr(shard, "fused_round0"):
+            shard.fused_round0(defer)   # round 0 out of the compress pass needs the constant-row exchange below
+        for width in widths:
+            flag = shard.scalar_tensor([1 if shard.compress(width) else 0])
+            if world > 1:
+                all_reduce(dist, flag, MIN)
+            if int(flag[0].item()) == 1:
+                break
+        else:
+            raise _ffi.TdError("row cost range exceeds 2^32-2 on some rank")
+        # constant rows (dummy cabs of a padded model) sit out the rounds and the searches, as in td_assign: one SUM
+        # all-reduce of an n-int mask tells every rank (the finisher's above all) which rows they are
+        if defer:
+            mask = shard.const_mask()
+            if world > 1:
+                all_reduce(dist, mask, SUM)
+            shard.set_const_mask(mask)
+        # the packed-key range guard needs the largest row range of ANY rank (td_assign's TD_ERANGE rule)
+        grange = -1
+        if hasattr(shard, "range"):
+            rt = shard.scalar_tensor([shard.range()])
+            if world > 1:
+                all_reduce(dist, rt, MAX)
+            grange = int(rt[0].item())
+        shard.begin(grange)
+    solve_sharded.last_left = left
+    if left == 0:
+        # every row that bids has its column: no rounds, no finisher, no peer mappings.  Deferred constant rows take the
+        # never-owned columns — the same placement on every rank from the replicated state — then on to the totals
+        if summ["nconst"] > 0:
+            shard.place_const()
+        return _sharded_totals(shard, dist, world, want_dual, False)
     # 2. Jacobi bidding rounds: ONE exchange step per round
     keys = shard.new_keys()
     if hasattr(shard, "native_comm") and getattr(shard, "shared_stream", False) and shard.native_comm(dist):
@@ -473,12 +558,18 @@ def _solve_sharded(shard, dist, rounds, want_dual, use_ipc):
         broadcast(dist, owner, 0)
         if rank != 0:
             shard.set_owner(owner)
-        if want_dual:  # the finisher moved prices on rank 0: the certificate needs them everywhere
-            price = shard.get_price() if rank == 0 else shard.empty_price()
-            broadcast(dist, price, 0)
-            if rank != 0:
-                shard.set_price(price)
     del refs
+    return _sharded_totals(shard, dist, world, want_dual, True)
+
+
+def _sharded_totals(shard, dist, world, want_dual, finisher_ran):
+    rank = dist.get_rank()
+    SUM = dist.ReduceOp.SUM
+    if world > 1 and want_dual and finisher_ran:  # the finisher moved prices on rank 0: the certificate needs them everywhere
+        price = shard.get_price() if rank == 0 else shard.empty_price()
+        broadcast(dist, price, 0)
+        if rank != 0:
+            shard.set_price(price)
     # 4. totals: each rank sums its own rows
     tot, dual = shard.totals(want_dual)
     t = shard.scalar_tensor([tot, dual])
@@ -488,6 +579,94 @@ def _solve_sharded(shard, dist, rounds, want_dual, use_ipc):
     if want_dual:
         return r2c, int(t[0].item()), int(t[1].item())
     return r2c, int(t[0].item())
+
+
+def solve_shards_in_process(shards, rounds=DEFAULT_ROUNDS, want_dual=True, blocks=True, call=None, fused_round0=True):
+    """The steps of solve_sharded over ALL the shards of an instance driven by one process on one GPU (tests, per-phase
+    timing: tools/r4_shard_time.py): torch.cat / torch.maximum stand in for the all-gather / the MAX all-reduce, the
+    library calls are the ones a rank makes.  `call(name, shard_index, fn)` wraps every library call (default: runs it).
+    Returns (row_to_col of all rows, total, dual, info)."""
+    import torch
+    call = call or (lambda name, k, fn: fn())
+    world, n = len(shards), shards[0].n
+    rps = shard_bounds(n, world, 0)[2]
+    sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)
+    info = {"path": "auction", "left": None}
+    left = None
+    can_blocks = shards[0].blocks_ok(n, world) if hasattr(shards[0], "blocks_ok") else blocks_ok(n, world)
+    if blocks and hasattr(shards[0], "phase_a") and can_blocks:
+        for s in shards:
+            s.blocks_start(True)
+        fits = [call("compress", k, lambda s=s: s.compress(1)) for k, s in enumerate(shards)]
+        for k, (s, f) in enumerate(zip(shards, fits)):
+            if f and s.blocks_pending():
+                call("phase_a", k, s.phase_a)
+        segs = [call("export", k, lambda s=s, f=f: s.state_segment(rps, f)) for k, (s, f) in enumerate(zip(shards, fits))]
+        allseg = torch.cat(segs)
+        sync()
+        summs = [call("import", k, lambda s=s, k=k: s.state_import(world, k, rps, allseg)) for k, s in enumerate(shards)]
+        assert all(x == summs[0] for x in summs), summs
+        if summs[0]["fit"] and summs[0]["ran"]:
+            left = summs[0]["left"]
+            for s in shards:
+                s.begin(summs[0]["range"])
+            info["path"] = "blocks"
+        else:
+            for s in shards:
+                s.blocks_start(False)
+    if left is None:
+        for s in shards:
+            if hasattr(s, "fused_round0"):
+                s.fused_round0(fused_round0)
+        for width in (1, 2, 4):
+            oks = [call("compress", k, lambda s=s: s.compress(width)) for k, s in enumerate(shards)]
+            if all(oks):
+                break
+        masks = [s.const_mask() for s in shards]
+        for m in masks[1:]:
+            masks[0] += m
+        sync()
+        for s in shards:
+            s.set_const_mask(masks[0])
+        grange = max(s.range() for s in shards) if hasattr(shards[0], "range") else -1
+        for k, s in enumerate(shards):
+            call("begin", k, lambda s=s: s.begin(grange))
+    info["left"] = left
+    finisher_ran = False
+    if left == 0 and summs[0]["nconst"] > 0:
+        for k, s in enumerate(shards):
+            call("place_const", k, s.place_const)
+    if left != 0:
+        keys = [s.new_keys() for s in shards]
+        for rnd in range(rounds):
+            for k, (s, ky) in enumerate(zip(shards, keys)):
+                call("bid%d" % rnd, k, lambda s=s, ky=ky: s.bid(rnd, ky))
+            red = keys[0].clone()
+            for ky in keys[1:]:
+                red = torch.maximum(red, ky)
+            sync()
+            for k, (s, ky) in enumerate(zip(shards, keys)):
+                ky.copy_(red)
+                sync()
+                call("apply%d" % rnd, k, lambda s=s, ky=ky: s.apply(rnd, ky))
+        call("finish", 0, lambda: shards[0].finish([s.cc_ref() for s in shards], rps))
+        finisher_ran = True
+        owner = shards[0].get_owner()
+        price = shards[0].get_price() if want_dual else None
+        sync()
+        for s in shards[1:]:
+            s.set_owner(owner)
+            if want_dual:
+                s.set_price(price)
+    tot = dual = 0
+    parts = []
+    for k, s in enumerate(shards):
+        t, d = call("totals", k, lambda s=s: s.totals(want_dual))
+        tot += t
+        dual += d
+        parts.append(s.row_to_col())
+    info["finisher_ran"] = finisher_ran
+    return np.concatenate(parts), tot, dual, info
 
 
 def assign_sharded(cost_rows, n, want_dual=False, rounds=DEFAULT_ROUNDS, dist=None):

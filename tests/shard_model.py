@@ -19,6 +19,7 @@ class ModelShard:
         self.width = 0
 
     def compress(self, width):
+        self._ready = False
         if self.nrows == 0:
             self.width = width
             self.rowmin = np.zeros(0, np.int64)
@@ -32,7 +33,96 @@ class ModelShard:
         self.cc = self.cost - self.rowmin[:, None]
         return True
 
+    # -- numpy model of the block-local start (csrc/td_blocks.h): phase A on the shard's own diagonal blocks (zero cells
+    #    only, no price moves), then ONE exchange of segments [16 header words | owners of the column slice | constant-row
+    #    flags].  Tie-breaks differ from the device's; the driver logic and the exactness argument are what is modelled.
+    def blocks_ok(self, n, world):
+        from taxidispatcher_amd import sharded
+        return sharded.BLOCKS % world == 0 and n % sharded.BLOCKS == 0 and n >= 2 * sharded.BLOCKS
+
+    def blocks_start(self, on=True):
+        self._blocks = bool(on)
+        self._ready = False
+
+    def blocks_pending(self):
+        return bool(getattr(self, "_blocks", False)) and self.width == 1
+
+    def phase_a(self):
+        from taxidispatcher_amd import sharded
+        n = self.n
+        rpb = n // sharded.BLOCKS
+        self.p = np.zeros(n, np.int64)
+        self.owner = np.full(n, -1, np.int64)
+        self.r2c = np.full(self.nrows, -1, np.int64)
+        self.r2c[self.cost.max(1) == self.cost.min(1)] = -2   # constant rows are deferred
+        for lb in range(self.nrows // rpb):
+            c0 = self.row0 + lb * rpb               # the block's columns = its rows' global ids
+            rows = range(lb * rpb, (lb + 1) * rpb)
+            for lr in rows:                          # greedy on the zero cells
+                if self.r2c[lr] != -1:
+                    continue
+                z = np.nonzero((self.cc[lr, c0:c0 + rpb] == 0) & (self.owner[c0:c0 + rpb] < 0))[0]
+                if len(z):
+                    j = c0 + int(z[(lr * 7) % len(z)])
+                    self.owner[j] = self.row0 + lr
+                    self.r2c[lr] = j
+            for lr in rows:                          # two hops: free row -> zero column -> its owner -> free zero column
+                if self.r2c[lr] != -1:
+                    continue
+                done = False
+                for j in c0 + np.nonzero(self.cc[lr, c0:c0 + rpb] == 0)[0]:
+                    r = int(self.owner[j]) - self.row0
+                    if r < 0:
+                        continue
+                    esc = np.nonzero((self.cc[r, c0:c0 + rpb] == 0) & (self.owner[c0:c0 + rpb] < 0))[0]
+                    if len(esc):
+                        jp = c0 + int(esc[0])
+                        self.owner[jp] = self.row0 + r
+                        self.r2c[r] = jp
+                        self.owner[j] = self.row0 + lr
+                        self.r2c[lr] = j
+                        done = True
+                        break
+                _ = done
+        self._ready = True
+
+    def place_const(self):
+        crow, fcol = np.nonzero(self.cmask)[0], np.nonzero(self.owner < 0)[0]
+        assert len(crow) == len(fcol)
+        owner = self.owner.copy()
+        owner[fcol] = crow
+        self.set_owner(torch.from_numpy(owner.astype(np.int32)))
+
+    def state_segment(self, rps, fits):
+        seg = np.zeros(16 + 2 * rps, np.int64)
+        ran = bool(getattr(self, "_ready", False))
+        rng = int((self.cost.max(1) - self.cost.min(1)).max()) if self.nrows else 0
+        seg[0:6] = [1 if fits else 0, 1 if ran else 0, int((self.r2c == -1).sum()) if ran else -1,
+                    int((self.cost.max(1) == self.cost.min(1)).sum()) if self.nrows else 0, rng & 0xFFFFFFFF, rng >> 32]
+        seg[16:16 + rps] = -1
+        if ran:
+            seg[16:16 + self.nrows] = self.owner[self.row0:self.row0 + self.nrows]
+        if self.nrows:
+            seg[16 + rps:16 + rps + self.nrows] = (self.cost.max(1) == self.cost.min(1))
+        return torch.from_numpy(seg.astype(np.int32))
+
+    def state_import(self, world, rank, rps, allseg):
+        a = allseg.numpy().astype(np.int64).reshape(world, 16 + 2 * rps)
+        n = self.n
+        cm = np.zeros(n, bool)
+        for r in range(world):
+            lo, hi = r * rps, min(n, (r + 1) * rps)
+            if r != rank and getattr(self, "_ready", False):
+                self.owner[lo:hi] = a[r, 16:16 + hi - lo]
+            cm[lo:hi] = a[r, 16 + rps:16 + rps + hi - lo] != 0
+        self.cmask = cm
+        left = sum(int(x) if x >= 0 else n for x in a[:, 2])
+        return {"fit": bool(a[:, 0].all()), "ran": bool(a[:, 1].all()), "left": left, "nconst": int(a[:, 3].sum()),
+                "range": int(((a[:, 5] << 32) | (a[:, 4] & 0xFFFFFFFF)).max())}
+
     def begin(self, global_range=-1):
+        if getattr(self, "_ready", False):   # phase A has initialised the state
+            return
         self.p = np.zeros(self.n, np.int64)
         self.owner = np.full(self.n, -1, np.int64)
         self.r2c = np.full(self.nrows, -1, np.int64)

@@ -148,9 +148,11 @@ def test_headline_size_other_families(td, kind):
 
 
 def test_config3_shard_geometry_in_process(td):
-    """BASELINE configs[3] with its REAL geometry: 8 row shards of 8 192 x 65 536 (2 GiB int32 each)
-    in one process, the per-round MAX all-reduce of the packed keys done in place with torch.maximum.
-    The sharded run must give 10*N with a closing certificate and the same row_to_col as td_assign."""
+    """BASELINE configs[3] with its REAL geometry: 8 row shards of 8 192 x 65 536 (2 GiB int32 each) in one process,
+    driven through the steps of solve_sharded (torch.cat / torch.maximum stand in for the collectives).  Both sequences:
+    the block-local start (csrc/td_blocks.h: phase A on every shard's diagonal block, ONE exchange, then whatever is
+    left) and the plain one (a MAX all-reduce of the packed keys per round, finisher on rank 0).  Each must give 10*N
+    with a closing certificate and the same row_to_col as td_assign with the same block setting."""
     import torch
     from taxidispatcher_amd import _ffi, sharded
     lib = _ffi.lib()
@@ -161,60 +163,27 @@ def test_config3_shard_geometry_in_process(td):
     full = torch.empty((n, n), dtype=torch.int32, device="cuda")
     _ffi.check(lib.td_gen_uniform(n, 7, 10, 40, 0, n, full.data_ptr()))
     _ffi.check(lib.td_synchronize())
-    shards = []
-    try:
-        for r in range(world):
-            row0, nrows, rps = sharded.shard_bounds(n, world, r)
-            shards.append(sharded.HipShard(n, row0, nrows, full[row0:row0 + nrows], share_torch_stream=False))
-        for s in shards:
-            s.fused_round0(True)   # as solve_sharded does: round 0's bids come out of the shards' compress passes
-        for width in (1, 2, 4):
-            if all([s.compress(width) for s in shards]):
-                break
-        masks = [s.const_mask() for s in shards]
-        for m in masks[1:]:
-            masks[0] += m
-        torch.cuda.synchronize()
-        for s in shards:
-            s.set_const_mask(masks[0])
-        grange = max(s.range() for s in shards)
-        for s in shards:
-            s.begin(grange)
-        keys = [s.new_keys() for s in shards]
-        for rnd in range(sharded.DEFAULT_ROUNDS):
-            for s, k in zip(shards, keys):
-                s.bid(rnd, k)
-            red = keys[0].clone()
-            for k in keys[1:]:
-                red = torch.maximum(red, k)
-            torch.cuda.synchronize()
-            for s, k in zip(shards, keys):
-                k.copy_(red)
-                torch.cuda.synchronize()
-                s.apply(rnd, k)
-        shards[0].finish([s.cc_ref() for s in shards], rps)
-        owner = shards[0].get_owner()
-        price = shards[0].get_price()
-        torch.cuda.synchronize()
-        tot = dual = 0
-        r2c = []
-        for s in shards[1:]:
-            s.set_owner(owner)
-            s.set_price(price)
-        for s in shards:
-            t, d = s.totals(True)
-            tot += t
-            dual += d
-            r2c.append(s.row_to_col())
-        r2c = np.concatenate(r2c)
-    finally:
-        for s in shards:
-            s.close()
-    assert tot == 10 * n == dual
-    assert sorted(r2c.tolist()) == list(range(n))
-    ref, ref_total = td.assign(full)
-    assert ref_total == 10 * n
-    assert np.array_equal(ref, r2c), "sharded and unsharded runs must be bit-identical"
+    for blocks in (True, False):
+        shards = []
+        try:
+            for r in range(world):
+                row0, nrows, rps = sharded.shard_bounds(n, world, r)
+                shards.append(sharded.HipShard(n, row0, nrows, full[row0:row0 + nrows], share_torch_stream=False))
+            r2c, tot, dual, info = sharded.solve_shards_in_process(shards, blocks=blocks)
+        finally:
+            for s in shards:
+                s.close()
+        assert info["path"] == ("blocks" if blocks else "auction")
+        assert tot == 10 * n == dual
+        assert sorted(r2c.tolist()) == list(range(n))
+        was = lib.td_set_blocks(8 if blocks else 0)
+        try:
+            ref, ref_total = td.assign(full)
+        finally:
+            lib.td_set_blocks(was)
+        assert ref_total == 10 * n
+        if not blocks or info["left"] == 0:   # (rows the blocks leave free go to the rounds here, to a two-hop pass over the whole matrix in td_assign)
+            assert np.array_equal(ref, r2c), "sharded and unsharded runs must be bit-identical"
 
 
 def test_shard_range_guard(td):

@@ -413,53 +413,14 @@ def test_solve_sharded_takes_the_line_path_under_rccl(td):
     assert out[0] == "line"
 
 
-def _drive_shards_in_process(torch, sharded, full, n, world, fused):
-    """the steps of solve_sharded over `world` shards in one process (torch.maximum = the MAX all-reduce)"""
+def _drive_shards_in_process(torch, sharded, full, n, world, fused, blocks=False):
+    """the steps of solve_sharded over `world` shards in one process (sharded.solve_shards_in_process)"""
     shards = []
     try:
         for r in range(world):
             row0, nrows, rps = sharded.shard_bounds(n, world, r)
             shards.append(sharded.HipShard(n, row0, nrows, full[row0:row0 + nrows], share_torch_stream=False))
-        for s in shards:
-            s.fused_round0(fused)
-        for width in (1, 2, 4):
-            if all([s.compress(width) for s in shards]):
-                break
-        masks = [s.const_mask() for s in shards]
-        for m in masks[1:]:
-            masks[0] += m
-        torch.cuda.synchronize()
-        for s in shards:
-            s.set_const_mask(masks[0])
-        grange = max(s.range() for s in shards)
-        for s in shards:
-            s.begin(grange)
-        keys = [s.new_keys() for s in shards]
-        for rnd in range(sharded.DEFAULT_ROUNDS):
-            for s, k in zip(shards, keys):
-                s.bid(rnd, k)
-            red = keys[0].clone()
-            for k in keys[1:]:
-                red = torch.maximum(red, k)
-            torch.cuda.synchronize()
-            for s, k in zip(shards, keys):
-                k.copy_(red)
-                torch.cuda.synchronize()
-                s.apply(rnd, k)
-        shards[0].finish([s.cc_ref() for s in shards], rps)
-        owner, price = shards[0].get_owner(), shards[0].get_price()
-        torch.cuda.synchronize()
-        tot = dual = 0
-        parts = []
-        for s in shards:
-            if s is not shards[0]:
-                s.set_owner(owner)
-                s.set_price(price)
-            t, d = s.totals(True)
-            tot += t
-            dual += d
-            parts.append(s.row_to_col())
-        return np.concatenate(parts), tot, dual
+        return sharded.solve_shards_in_process(shards, blocks=blocks, fused_round0=fused)   # fused False: round 0 as its own k_bid launch
     finally:
         for s in shards:
             s.close()
@@ -485,11 +446,61 @@ def test_fused_round0_in_shards_is_bit_identical(td, kind):
     b = _drive_shards_in_process(torch, sharded, full, n, world, False)
     assert a[1] == a[2] == b[1] == b[2]
     assert np.array_equal(a[0], b[0])
-    ref, ref_total, ref_dual = td.assign(full, want_dual=True)
+    assert a[3]["path"] == b[3]["path"] == "auction"     # three ranks do not own whole diagonal blocks
+    was = _ffi_lib().td_set_blocks(0)                       # td_assign without the block-local start: the same sequence
+    try:
+        ref, ref_total, ref_dual = td.assign(full, want_dual=True)
+    finally:
+        _ffi_lib().td_set_blocks(was)
     assert ref_total == a[1] == ref_dual
     if kind != "padded":    # (td_assign may solve a padded model transposed: another optimum among the ties)
         assert np.array_equal(ref, a[0])
     assert sorted(a[0].tolist()) == list(range(n))
+
+
+def _ffi_lib():
+    from taxidispatcher_amd import _ffi
+    return _ffi.lib()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,world", [("g1", 8), ("g1", 2), ("padded", 4), ("uniq", 8), ("wide", 2), ("ties", 1)])
+def test_block_local_start_in_shards(td, kind, world):
+    """csrc/td_blocks.h through the shard API (n = 12 288: the smallest size whose compress pass writes the zero-slice
+    bids): phase A on every shard's own diagonal blocks, ONE exchange, the ordinary rounds and the finisher for what is
+    left.  Optimal (total == dual bound), a permutation, and — when phase A left nothing, which is when both sequences
+    coincide — td_assign's row_to_col with the same 8 blocks, bit for bit.  "wide" does not fit one byte: every shard
+    learns it from the exchanged segments and the plain sequence runs."""
+    import torch
+    from taxidispatcher_amd import sharded
+    n = 12288
+    g = torch.Generator(device="cuda").manual_seed(17)
+    if kind == "uniq":      # one cell at the minimum of every row: phase A places the rows whose minimum lies in their own block
+        full = torch.randint(3, 200, (n, n), dtype=torch.int32, device="cuda", generator=g)
+        full[torch.arange(n, device="cuda"), torch.randint(0, n, (n,), device="cuda", generator=g)] = 0
+    elif kind == "wide":
+        full = torch.randint(0, 1000, (n, n), dtype=torch.int32, device="cuda", generator=g)
+    elif kind == "ties":
+        full = torch.randint(0, 3, (n, n), dtype=torch.int32, device="cuda", generator=g)
+    else:
+        full = torch.randint(10, 41, (n, n), dtype=torch.int32, device="cuda", generator=g)
+        if kind == "padded":
+            full[torch.randperm(n, device="cuda", generator=g)[: n // 4]] = 250
+    r2c, tot, dual, info = _drive_shards_in_process(torch, sharded, full, n, world, True, blocks=True)
+    assert info["path"] == ("auction" if kind == "wide" else "blocks")
+    assert tot == dual
+    assert sorted(r2c.tolist()) == list(range(n))
+    assert int(full[torch.arange(n, device="cuda"), torch.from_numpy(r2c).cuda().long()].long().sum().item()) == tot
+    was = _ffi_lib().td_set_blocks(8)
+    try:
+        ref, ref_total, ref_dual = td.assign(full, want_dual=True)
+    finally:
+        _ffi_lib().td_set_blocks(was)
+    assert ref_total == tot == ref_dual
+    if kind == "g1":
+        assert tot == 10 * n
+    if info["left"] == 0 and kind not in ("padded", "wide"):
+        assert np.array_equal(ref, r2c)
 
 
 def _fused_worker(rank, world, port, n, seed, q):
@@ -512,7 +523,7 @@ def _fused_worker(rank, world, port, n, seed, q):
         path = sharded.solve_sharded.last_path
     finally:
         sh.close()
-    q.put((rank, np.asarray(r2c).tolist(), int(total), int(dual), path))
+    q.put((rank, np.asarray(r2c).tolist(), int(total), int(dual), path, sharded.solve_sharded.last_left))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -538,5 +549,8 @@ def test_two_ranks_wide_shards_fused_round0(td):
     _ffi.check(_ffi.lib().td_gen_uniform(n, seed, 10, 40, 0, n, full.data_ptr()))
     ref, ref_total, ref_dual = td.assign(full, want_dual=True)
     assert outs[0][2] == outs[1][2] == ref_total == ref_dual == outs[0][3] == outs[1][3]
-    assert outs[0][4] == outs[1][4] == "auction"
-    assert np.array_equal(np.array(outs[0][1] + outs[1][1]), ref)
+    assert outs[0][4] == outs[1][4] == "blocks"     # two ranks own four diagonal blocks each: the block-local start
+    got = np.array(outs[0][1] + outs[1][1])
+    assert sorted(got.tolist()) == list(range(n))
+    if outs[0][5] == 0:   # phase A left nothing: the same sequence as td_assign's (8 blocks by default at this size)
+        assert np.array_equal(got, ref)

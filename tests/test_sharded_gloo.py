@@ -108,11 +108,16 @@ def test_three_ranks_uneven_shards():
     assert sorted(r3.tolist()) == list(range(n))
 
 
-@pytest.mark.parametrize("world,kind,n,path", [(2, "g2", 61, "line"), (3, "g2", 50, "line"), (2, "g1", 40, "auction"),
-                                               (2, "g3", 64, "auction"), (3, "g2dup", 47, "line")])
+@pytest.mark.parametrize("world,kind,n,path", [(2, "g2", 61, "line"), (3, "g2", 50, "line"), (2, "g1", 42, "auction"),
+                                               (2, "g3", 64, "auction"), (3, "g2dup", 47, "line"),
+                                               (2, "g1", 40, "blocks"), (4, "g1", 64, "blocks"), (2, "padded", 72, "blocks"),
+                                               (8, "padded", 48, "blocks")])
 def test_sharded_line_path_over_ranks(world, kind, n, path):
     """the sorted matching over row shards (four SUM all-reduces of O(n) words): taken for |a - b| matrices, refused
-    (and the auction run) for the others; duplicates in the positions do not matter"""
+    (and the auction run) for the others; duplicates in the positions do not matter.  "blocks": the 1-byte attempt
+    started on every rank's own diagonal blocks and the ranks met in ONE all-gather (csrc/td_blocks.h; n a multiple of
+    8, 8 a multiple of the world size); g3 does not fit one byte: every rank learns it from the same all-gather and the
+    ordinary sequence runs from the 2-byte width"""
     from oracle import oracle
     if kind == "g2dup":
         rng = np.random.default_rng(3)

@@ -13,6 +13,9 @@ kinds = {}
 while time.time() < t_end:
     kind = ["g1", "ties", "r250", "uniq", "padrows", "padcols", "padboth", "thresh", "rowshift"][int(rng.integers(0, 9))]
     n = 4 * int(rng.integers(3072, 5200)) if rng.random() < 0.8 else 4 * int(rng.integers(5200, 8200))
+    if os.environ.get("STRESS_ALIGN"):   # STRESS_ALIGN=128: sizes the block-local start (td_blocks.h, 8 blocks) applies to
+        al = int(os.environ["STRESS_ALIGN"])
+        n = (n + al - 1) // al * al
     kinds[kind] = kinds.get(kind, 0) + 1
     if kind == "g1":
         c = torch.randint(10, 41, (n, n), dtype=torch.int32, device="cuda")
