@@ -165,7 +165,10 @@ TD_API int td_lcm_shard_round_commit(td_lcm_shard *s, const int64_t *taken);
  *   *lcm_last_min (LCM_min_val, Simulator.java:188), kept_cabs / kept_dems (may be NULL: positions of the cabs /
  *   requests left for the solver, in order), *n_rest = max of their counts, row_to_col[n_rest] and the total of
  *   the remainder's optimal assignment (dummy cells count fill, like td_assign).  An empty model returns 0 pairs,
- *   n_rest 0.  The cost matrices are library buffers in HBM (td_tick_release_workspace frees them). */
+ *   n_rest 0.  When the LCM ran and ended on `fill` (*lcm_last_min == fill) the tick has no input for the solver,
+ *   as in Simulator.java:188-189: the pairs, the kept lists and *n_rest are reported, row_to_col is left untouched and
+ *   *total is 0.  row_to_col indexes the kept lists: ask for kept_cabs / kept_dems whenever it is used.
+ *   The cost matrices are library buffers in HBM (td_tick_release_workspace frees them). */
 TD_API int td_tick(const int32_t *cab_to, int n_s, const int32_t *dem_from, int n_d, const int32_t *dist, int S, int32_t fill,
                    int32_t threshold, int stop_size, int32_t *lcm_rows, int32_t *lcm_cols, int32_t *n_pairs,
                    int32_t *lcm_last_min, int32_t *kept_cabs, int32_t *kept_dems, int32_t *n_rest, int32_t *row_to_col,

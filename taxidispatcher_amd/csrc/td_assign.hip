@@ -1279,12 +1279,14 @@ __global__ __launch_bounds__(256) void k_compress_tr8(int n, int npad, const int
 }
 
 __global__ void k_tr_finish(int n, int base, const int *__restrict__ colmin, const int *__restrict__ colmax, int32_t *__restrict__ rowmin,
-                            int *__restrict__ rconst, int *__restrict__ ctl, int esc_raw = 0, int with_esc = 0)
+                            int *__restrict__ rconst, int *__restrict__ ctl, int esc_raw = 0, int with_esc = 0,
+                            long long assumed_range = -1 /* >= 0: the speculative pass went on as if every cell were <= base + this (32-bit prices, BIG = 2^28): a larger cell voids the attempt */)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j == 0 && with_esc) g_esc8 = (uint32_t)(esc_raw - base);
     if (j >= n) return;
     const int mn = colmin[j], mx = colmax[j];
+    if (assumed_range >= 0 && (long long)mx - (long long)base > assumed_range) atomicOr(&ctl[CTL_FLAG], 1);
     rowmin[j] = base;
     const int cst = (mn == mx) ? 1 : 0;
     rconst[j] = cst;
@@ -3099,7 +3101,8 @@ int sv_compress(Solver &sv, int bpc, bool *fits, bool speculate = false)
 }
 
 // padded model: the transposed problem's 4-byte cells straight from the caller's matrix (k_compress_tr)
-int sv_compress_fused(Solver &sv, bool *fits, int64_t *range, bool cells8 = false, int esc_raw = 0, bool nosync = false)
+int sv_compress_fused(Solver &sv, bool *fits, int64_t *range, bool cells8 = false, int esc_raw = 0, bool nosync = false,
+                      int64_t assumed_range = -1 /* nosync: the range the caller goes on with (a padded matrix whose real cells exceed the pad value) */)
 {
     Ctx &c = ctx();
     const int n = sv.n;
@@ -3131,7 +3134,7 @@ int sv_compress_fused(Solver &sv, bool *fits, int64_t *range, bool cells8 = fals
         else
             k_compress_tr<1><<<dim3((n + 63) / 64, (n + 63) / 64), 256, 0, c.stream>>>(n, npad, sv.d_cost, (uint32_t *)sv.cc.p, 0, colmin, colmax, ctl);
         k_tr_finish<<<(n + 255) / 256, 256, 0, c.stream>>>(n, 0, colmin, colmax, (int32_t *)sv.rowmin.p, (int *)sv.rconst.p, ctl, esc_raw,
-                                                           cells8 ? 1 : 0);
+                                                           cells8 ? 1 : 0, nosync ? (long long)assumed_range : -1ll);
     }
     TD_HIP(hipGetLastError());
     if (nosync) {   // speculative like the 1-byte attempt of a square model: the flags come home with the final read-back
@@ -3759,6 +3762,10 @@ void td::assign_hint_padded(int const_cols, int const_rows, int32_t fill)
 // =====================================================================================
 extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_t *total, int64_t *dual_bound)
 {
+    // the hint of td_tick is for THIS call only, whatever way the call ends (an early return left it for the
+    // next, unrelated call)
+    const AssignHint hint = g_hint;
+    g_hint.valid = false;
     TD_REQUIRE_INIT();
     Ctx &c = ctx();
     read_tunables();
@@ -3798,8 +3805,6 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     bool line_pending = false, early_check = false, r2c_in_pinned = false;
     constexpr size_t R2C_PIN_OFF = 8192;   // clear of the control words (0..), the totals (1024) and the probe verdict (4096)
     c.stats[8] = c.stats[9] = 0;
-    const AssignHint hint = g_hint;
-    g_hint.valid = false;
     const int hint_margin = n / 256 > 32 ? n / 256 : 32;
     const bool hinted_fuse = hint.valid && g_fuse_t && g_shape && !g_solver_eps && n >= 64 && hint.const_cols >= 16 &&
                              hint.const_cols - hint.const_rows >= hint_margin && hint.fill >= 255 && (int64_t)hint.fill <= NP_RANGE;
@@ -3819,10 +3824,10 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         int64_t fr = 0;
         fused_spec = true;
         if (g_fuse_t >= 2 && n > 2048 && n <= 65536) {
-            if ((rc = sv_compress_fused(sv, &ff, &fr, true, hint.fill, true))) return rc;
+            if ((rc = sv_compress_fused(sv, &ff, &fr, true, hint.fill, true, hint.fill))) return rc;
             sv.fused8 = ff;
         }
-        if (!ff && (rc = sv_compress_fused(sv, &ff, &fr, false, 0, true))) return rc;
+        if (!ff && (rc = sv_compress_fused(sv, &ff, &fr, false, 0, true, hint.fill))) return rc;
         sv.fused_t = true;
         transposed = true;
         hinted_range = hint.fill;
@@ -3884,10 +3889,10 @@ restart:
                     fused_spec = g_fuse_spec && shape3[3] >= 255 && (int64_t)shape3[3] <= NP_RANGE;
                     // 1-byte cells + escape first ({small range} u {fill}: every reference model of this kind), else 4-byte cells
                     if (g_fuse_t >= 2 && n > 2048 && n <= 65536) {   // a small model is launch-bound: 64 x 1024 tiles leave most CUs idle (tick: 0.465 vs 0.432 ms)
-                        if ((rc = sv_compress_fused(sv, &ff, &fr, true, shape3[3], fused_spec))) return rc;
+                        if ((rc = sv_compress_fused(sv, &ff, &fr, true, shape3[3], fused_spec, shape3[3]))) return rc;
                         sv.fused8 = ff;
                     }
-                    if (!ff && (rc = sv_compress_fused(sv, &ff, &fr, false, 0, fused_spec))) return rc;
+                    if (!ff && (rc = sv_compress_fused(sv, &ff, &fr, false, 0, fused_spec, shape3[3]))) return rc;
                     if (fused_spec) fr = shape3[3];
                     if (getenv("TD_DEBUG")) fprintf(stderr, "[td] fused transpose + compress: n=%d fits %d range %lld, %d constant rows\n", n, (int)ff, (long long)fr, sv.nconst);
                     if (ff) {

@@ -192,7 +192,11 @@ extern "C" int td_tick(const int32_t *cab_to, int n_s, const int32_t *dem_from, 
     int32_t *hp = (int32_t *)t.pin;
     TD_HIP(hipMemcpyAsync(hp, d_keep_c, sizeof(int32_t) * (2 * (size_t)n + 2), hipMemcpyDeviceToHost, c.stream));
     *n_rest = n2;
-    if (n2 > 0) {
+    // Simulator.java:188-189: when the LCM ended on big_cost ("no input for the solver; continue") the reference does
+    // not call the solver in this tick.  The pairs, LCM_min_val and the kept lists are reported, row_to_col and
+    // *total (0) are not touched; the caller sees it as lcm_last_min == fill with the LCM having run.
+    const bool lcm_ran = stop_size >= 0 && stop_size < n;
+    if (n2 > 0 && !(lcm_ran && last_min == fill)) {
         if ((rc = ensure(t.cost_b, sizeof(int32_t) * (size_t)n2 * n2))) return rc;
         int32_t *d_b = (int32_t *)t.cost_b.p;
         if ((rc = td_cost_build(d_cab2, nullptr, kc, d_dem2, nullptr, kd, d_dist, S, fill, threshold, 0, d_b))) return rc;

@@ -230,7 +230,8 @@ def tick(cab_to, dem_from, distances=None, big_cost=BIG_COST, drop_time=10, max_
     stand at / the requests start from.  Returns a dict: lcm_rows, lcm_cols (int32 arrays, the reference's pick
     order), lcm_min_val, kept_cabs, kept_dems (positions handed to the solver, in order), n_rest, row_to_col
     (int32[n_rest], indices into kept_cabs -> kept_dems; >= len(kept_dems) or a cab index >= len(kept_cabs): dummy),
-    total (the remainder's optimum, dummy cells count big_cost)."""
+    total (the remainder's optimum, dummy cells count big_cost), solved (False when the LCM ran and ended on big_cost:
+    like Simulator.java:188-189 the tick then has no input for the solver; row_to_col is empty and total 0)."""
     lib = _ffi.lib()
     cab = cab_to if hasattr(cab_to, "data_ptr") else _ffi.as_i32(cab_to)
     dem = dem_from if hasattr(dem_from, "data_ptr") else _ffi.as_i32(dem_from)
@@ -249,8 +250,11 @@ def tick(cab_to, dem_from, distances=None, big_cost=BIG_COST, drop_time=10, max_
                            ctypes.byref(n2), _ffi.addr(r2c), ctypes.byref(tot)))
     del keep
     kk = k.value
+    lcm_ran = max_non_lcm is not None and 0 <= int(max_non_lcm) < n
+    solved = n2.value > 0 and not (lcm_ran and lm.value == int(big_cost))
     return {"lcm_rows": rows[:kk], "lcm_cols": cols[:kk], "lcm_min_val": lm.value, "kept_cabs": kc[:n_s - kk],
-            "kept_dems": kd[:n_d - kk], "n_rest": n2.value, "row_to_col": r2c[:n2.value], "total": tot.value}
+            "kept_dems": kd[:n_d - kk], "n_rest": n2.value, "row_to_col": r2c[:n2.value if solved else 0], "total": tot.value,
+            "solved": solved}
 
 
 def find_pool(frm, to, distances=None):

@@ -694,6 +694,7 @@ def pool_fanout(k, demand, dist, children=8, finder=None, merger=None, timeout=6
     points; the gloo test injects host models."""
     import datetime
     import pickle
+    import time
     if finder is None or merger is None:
         from . import dispatch
         finder = finder or (lambda kk, dd, child: dispatch.find_pool_n(kk, dd, child=child, children=children)[0])
@@ -720,17 +721,26 @@ def pool_fanout(k, demand, dist, children=8, finder=None, merger=None, timeout=6
             lists.update(pickle.loads(store.get(kk)))
         out = np.asarray(merger(k, len(demand), [lists[t] for t in range(children)])).reshape(-1, 2 * k + 1).tolist()
         store.set(key + "result", pickle.dumps(("ok", out)))
-        for kk in keys:
+        # the readers acknowledge; the last one (or, after the timeout, nobody) leaves rank 0 to delete the keys of this
+        # call — a long simulation does not pile one merged list per tick up in the store
+        deadline = time.monotonic() + float(timeout)
+        while world > 1 and store.add(key + "ack", 0) < world - 1 and time.monotonic() < deadline:
+            time.sleep(0.0005)
+        for kk in keys + [key + "result", key + "ack"]:
             try:
                 store.delete_key(kk)
             except Exception:
                 pass
     else:
+        # rank 0 may still be in its own finder when this rank is done, then waits up to `timeout` for the slowest rank
+        # and merges: its answer is due within two timeouts of NOW (a wait of timeout + 5 s measured from this rank's
+        # finish could expire on a healthy run)
         try:
-            store.wait([key + "result"], limit + datetime.timedelta(seconds=5))
+            store.wait([key + "result"], limit + limit + datetime.timedelta(seconds=5))
         except Exception:
-            raise _ffi.TdError("pool fan-out: rank 0 did not hand the merged pools back within %.0f s" % (float(timeout) + 5))
+            raise _ffi.TdError("pool fan-out: rank 0 did not hand the merged pools back within %.0f s" % (2 * float(timeout) + 5))
         status, out = pickle.loads(store.get(key + "result"))
+        store.add(key + "ack", 1)
         if status != "ok":
             raise _ffi.TdError("pool fan-out: rank(s) %s did not deliver their slices within %.0f s" % (out, float(timeout)))
     return np.asarray(out, np.int32).reshape(-1, 2 * k + 1)
@@ -770,6 +780,10 @@ class HipLcmShard:
         self._fence(out)
 
     def round_apply(self, limit, colmin, out):
+        # `colmin` comes out of torch work (torch.minimum over in-process shards, the MIN all-reduce): RCCL and torch
+        # order that on torch's stream only, the library's kernel runs on its own — wait for it first (ADVICE r3:
+        # without this k_lcmsh_apply could read a partially reduced vector on a multi-GPU run)
+        self._fence(colmin)
         _ffi.check(self.lib.td_lcm_shard_round_apply(self.h, int(limit), _ffi.addr(colmin), _ffi.addr(out)))
         self._fence(out)
 
@@ -782,6 +796,7 @@ class HipLcmShard:
             torch.cuda.synchronize(t.device)
 
     def round_commit(self, taken):
+        self._fence(taken)   # (torch.maximum / the MAX all-reduce that produced `taken`)
         _ffi.check(self.lib.td_lcm_shard_round_commit(self.h, _ffi.addr(taken)))
 
     def close(self):

@@ -45,6 +45,37 @@ class HipBackend:
         return self.d.find_pool(frm, to, None)
 
 
+class HipTickBackend(HipBackend):
+    """The same path with ONE C-ABI call per tick (td_tick = Simulator.java:163-208 behind one entry point: cost build ->
+    LCM -> removal of the matched cabs / requests on the device -> cost build -> optimal assignment); the harness
+    only applies the pairs and the solution to its world."""
+
+    def tick(self, cab_to, dem_from):
+        return self.d.tick(np.asarray(cab_to, np.int32), np.asarray(dem_from, np.int32), None, big_cost=BIG_COST,
+                           drop_time=DROP_TIME, max_non_lcm=MAX_NON_LCM)
+
+
+class _RealCells:
+    """cost[s][c] of a model that stayed on the device, as far as analyzeSolution reads it (Simulator.java:508-511: a
+    cell is dist[cab.to][request.from] when that is below DROP_TIME, else big_cost)"""
+
+    def __init__(self, supply, demand):
+        self.supply, self.demand = supply, demand
+
+    def __getitem__(self, s):
+        to = self.supply[s][2]
+        return _RealRow(to, self.demand)
+
+
+class _RealRow:
+    def __init__(self, to, demand):
+        self.to, self.demand = to, demand
+
+    def __getitem__(self, c):
+        d = abs(self.to - self.demand[c][1])
+        return d if d < DROP_TIME else BIG_COST
+
+
 def read_demand(path):
     """taxi_demand.txt rows `(id,from,to,time,at)` (Simulator.java:280-304, gendemand.py:19)."""
     op = gzip.open if str(path).endswith(".gz") else open
@@ -266,6 +297,8 @@ class Simulator:
         line = "t:%d. Initial Count of demand=%d, supply=%d. " % (t, len(temp_demand), len(temp_supply))
         cost = np.zeros((0, 0), np.int32)
         r2c = []
+        if temp_supply and hasattr(self.be, "tick"):
+            return self._tick_one_call(t, line, temp_demand, temp_supply)
         if temp_supply:
             temp_demand = self.analyze_pool(self.find_pool(temp_demand), temp_demand)
             cost = self.calculate_cost(temp_demand, temp_supply)
@@ -284,6 +317,30 @@ class Simulator:
                 self.on_solver_instance(t, temp_supply, temp_demand, cost)
             r2c = self.be.solve(cost)
         count = self.analyze_solution(t, r2c, cost, temp_demand, temp_supply)
+        return line + "; OPT count=%d" % count
+
+    # ---- the same tick (Simulator.java:163-208) with the whole path behind ONE backend call (td_tick)
+    def _tick_one_call(self, t, line, temp_demand, temp_supply):
+        temp_demand = self.analyze_pool(self.find_pool(temp_demand), temp_demand)
+        n = max(len(temp_demand), len(temp_supply))
+        self.m["max_model_size"] = max(self.m["max_model_size"], n)
+        res = self.be.tick([s[2] for s in temp_supply], [d[1] for d in temp_demand])
+        if n > MAX_NON_LCM:
+            self.m["total_LCM_used"] += 1
+            pairs = list(zip(res["lcm_rows"].tolist(), res["lcm_cols"].tolist()))
+            line += "LCM n_pairs=%d" % len(pairs)
+            kept_supply, kept_demand = self.analyze_pairs(t, pairs, temp_demand, temp_supply)
+            # the device's shrink (k_tick_shrink) and analyzePairs' removal must agree
+            assert [s[0] for s in kept_supply] == [temp_supply[k][0] for k in res["kept_cabs"].tolist()]
+            assert [d[0] for d in kept_demand] == [temp_demand[k][0] for k in res["kept_dems"].tolist()]
+            temp_supply, temp_demand = kept_supply, kept_demand
+            if not res["solved"]:                # :188 no input for the solver
+                return line
+            line += ". Sent to solver: demand=%d, supply=%d. " % (len(temp_demand), len(temp_supply))
+        self.m["max_solver_size"] = max(self.m["max_solver_size"], res["n_rest"])
+        r2c = res["row_to_col"]
+        # analyzeSolution reads cost[s][c] < big_cost (:378-383): a real cell of the thresholded |a - b| model
+        count = self.analyze_solution(t, r2c, _RealCells(temp_supply, temp_demand), temp_demand, temp_supply)
         return line + "; OPT count=%d" % count
 
     # ---- Simulator.java:256-277 printMetrics (wall-clock lines are the caller's: pass them in)

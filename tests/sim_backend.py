@@ -51,3 +51,25 @@ class OracleBackend:
             if len(out) * 2 >= n - 1:
                 break
         return out
+
+
+class OracleTickBackend(OracleBackend):
+    """the one-call-per-tick backend interface (HipTickBackend.tick = td_tick) on the oracle: the pipeline of
+    Simulator.java:163-208 with the solver skipped when the LCM ends on big_cost (:188-189)"""
+
+    def tick(self, cab_to, dem_from):
+        cab_to, dem_from = np.asarray(cab_to), np.asarray(dem_from)
+        n, cost = oracle.cost_build(cab_to, dem_from, None, BIG_COST, DROP_TIME)
+        rows = cols = np.zeros(0, np.int64)
+        lm, ran = BIG_COST, False
+        if n > MAX_NON_LCM:
+            _, rows, cols, lm = oracle.lcm(cost, mask=BIG_COST, stop_value_on=1, stop_value=BIG_COST, stop_size=MAX_NON_LCM,
+                                           sum_below=BIG_COST, java_scan=1)
+            ran = True
+        kc = np.setdiff1d(np.arange(len(cab_to)), rows)
+        kd = np.setdiff1d(np.arange(len(dem_from)), cols)
+        n2, cost2 = oracle.cost_build(cab_to[kc], dem_from[kd], None, BIG_COST, DROP_TIME)
+        solved = n2 > 0 and not (ran and lm == BIG_COST)
+        tot, r2c = (oracle.assign(cost2)[:2] if solved else (0, np.zeros(0, np.int32)))
+        return {"lcm_rows": np.asarray(rows), "lcm_cols": np.asarray(cols), "lcm_min_val": lm, "kept_cabs": kc, "kept_dems": kd,
+                "n_rest": n2, "row_to_col": r2c, "total": tot, "solved": solved}

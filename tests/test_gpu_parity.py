@@ -279,6 +279,29 @@ def test_rectangular_models_constant_rows_and_columns(td):
     assert seen_t >= 10   # the transposed path was exercised
 
 
+@pytest.mark.parametrize("n,pad,top", [(700, 1000, 3 * 10**8), (1500, 300, 2**22 + 5000), (3000, 1000, 10**6), (2500, 255, 5000)])
+def test_padded_model_whose_real_cells_exceed_the_pad_value(td, n, pad, top):
+    """the speculative fused transpose + compress pass takes the value of the (constant) last column for the
+    model's range and goes on with 32-bit prices; a model padded with a SMALL value whose real cells are larger (up to
+    beyond 2^28, the 32-bit kernels' BIG) must be caught on the device (k_tr_finish against the assumed range) and
+    redone on the general path — same optimum as the oracle, closing certificate.  The line attempt is ON here (the
+    default flow: its probe is what estimates the pad value)."""
+    was = td.set_line_metric(True)
+    try:
+        rng = np.random.default_rng(n)
+        real_c = n // 3
+        c = np.full((n, n), pad, np.int32)
+        c[:, :real_c] = rng.integers(0, top, (n, real_c)).astype(np.int32)
+        r2c, total, dual = td.assign(c, n, want_dual=True)
+        t_o = oracle.assign(c)[0]
+        assert total == t_o == dual, (total, t_o, dual, td.last_stats())
+        r2c = np.asarray(r2c)
+        assert sorted(r2c.tolist()) == list(range(n))
+        assert int(c[np.arange(n), r2c].astype(np.int64).sum()) == t_o
+    finally:
+        td.set_line_metric(was)
+
+
 def test_lcm_randomized_differential(td):
     """td_lcm against the oracle over random shapes of every stop rule: threshold, stop value,
     stop size, pair cap, masked cells, exhausted lists; instances with few value levels take the

@@ -35,6 +35,15 @@ def test_replay_matches_reference_log_oracle_backend():
     assert sim.m["max_model_size"] <= 1300 and sim.m["max_solver_size"] == 600
 
 
+def test_replay_one_call_per_tick_harness_oracle_backend():
+    """the harness path that hands a whole tick to ONE backend call (what HipTickBackend / td_tick serve on the GPU),
+    driven by the oracle's pipeline: the reference's log t = 0 ... 49 again, line by line"""
+    from sim_backend import OracleTickBackend
+    from taxidispatcher_amd import simulator
+    sim = simulator.Simulator(simulator.read_demand(os.path.join(GOLD, "taxi_demand.txt.gz")), OracleTickBackend())
+    assert [l.strip() for l in sim.run(50)] == golden_lines()
+
+
 def test_tick49_instance_oracle():
     from oracle import oracle
     g = tick49()
@@ -51,6 +60,21 @@ def test_replay_matches_reference_log_gpu(td):
     sim = simulator.Simulator(simulator.read_demand(os.path.join(GOLD, "taxi_demand.txt.gz")))  # HipBackend
     log = [l.strip() for l in sim.run(50)]
     assert log == golden_lines()
+
+
+@pytest.mark.gpu
+def test_replay_matches_reference_log_gpu_one_call_per_tick(td):
+    """The reference's committed log (simulations/simulog_solv.txt:2-51) replayed with ONE td_tick call per tick
+    (Simulator.java:163-208 behind one C-ABI entry point: cost build -> LCM -> device shrink -> cost build -> optimal
+    assignment); every line t = 0 ... 49 must come out as the reference wrote it, incl. the ticks whose LCM ends on
+    big_cost and therefore hand nothing to the solver (:188-189) and the first solver call's `OPT count=32`."""
+    from taxidispatcher_amd import simulator
+    sim = simulator.Simulator(simulator.read_demand(os.path.join(GOLD, "taxi_demand.txt.gz")), simulator.HipTickBackend())
+    log = [l.strip() for l in sim.run(50)]
+    gold = golden_lines()
+    assert log == gold
+    assert gold[49].endswith("Sent to solver: demand=218, supply=600. ; OPT count=32")
+    assert sim.m["max_solver_size"] == 600 and sim.m["total_LCM_used"] > 0
 
 
 @pytest.mark.gpu
@@ -128,7 +152,11 @@ def test_config5_tick_in_one_call_gpu(td):
         if len(rows):
             assert t["lcm_min_val"] == lm
         assert t["kept_cabs"].tolist() == keep_c.tolist() and t["kept_dems"].tolist() == keep_d.tolist()
-        assert t["n_rest"] == n2 and t["total"] == tot
+        assert t["n_rest"] == n2
+        if len(rows) and lm == BIG_COST:   # Simulator.java:188-189: the LCM ended on big_cost, nothing goes to the solver
+            assert not t["solved"] and t["total"] == 0 and len(t["row_to_col"]) == 0
+            continue
+        assert t["solved"] and t["total"] == tot
         r2c = t["row_to_col"]
         assert sorted(r2c.tolist()) == list(range(n2))
         assert int(cost2[np.arange(n2), r2c].astype(np.int64).sum()) == tot

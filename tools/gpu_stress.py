@@ -11,7 +11,8 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 120
 cnt = bad = 0
 slow = []
-while time.time() < t_end:
+max_cnt = int(sys.argv[3]) if len(sys.argv) > 3 else 10**9   # optional: stop after this many instances (tests/test_gpu_stress.py)
+while time.time() < t_end and cnt < max_cnt:
     kind = ["g1", "g4", "g2", "g3", "wide", "neg", "const", "rect", "line", "lineu", "linep"][int(rng.integers(0, 11))]
     n = int(rng.integers(2, 1400)) if kind not in ("g2", "wide") else int(rng.integers(2, 700))
     if kind == "rect":   # padded rectangular model: constant rows / columns, sometimes permuted

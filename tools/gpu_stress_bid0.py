@@ -10,7 +10,8 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 120)
 cnt = bad = 0
 kinds = {}
-while time.time() < t_end:
+max_cnt = int(sys.argv[3]) if len(sys.argv) > 3 else 10**9   # optional: stop after this many instances (tests/test_gpu_stress.py)
+while time.time() < t_end and cnt < max_cnt:
     kind = ["g1", "ties", "r250", "uniq", "padrows", "padcols", "padboth", "thresh", "rowshift"][int(rng.integers(0, 9))]
     n = 4 * int(rng.integers(3072, 5200)) if rng.random() < 0.8 else 4 * int(rng.integers(5200, 8200))
     if os.environ.get("STRESS_ALIGN"):   # STRESS_ALIGN=128: sizes the block-local start (td_blocks.h, 8 blocks) applies to

@@ -9,7 +9,8 @@ td.init(0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 120)
 cnt = bad = 0
-while time.time() < t_end:
+max_cnt = int(sys.argv[3]) if len(sys.argv) > 3 else 10**9   # optional: stop after this many instances (tests/test_gpu_stress.py)
+while time.time() < t_end and cnt < max_cnt:
     kind = ["wide", "g2", "mid", "rect", "g1", "g2gen", "geo2", "g2u"][int(rng.integers(0, 8))]
     n = int(rng.integers(4096, 12289))
     td.set_line_metric(kind != "g2gen")   # g2gen: the general solver alone on the |a-b| geometry
