@@ -386,8 +386,15 @@ def cpu_baseline(kind, n_gpu, seconds):
         t0 = time.perf_counter()
         if kind == "g1":
             c = oracle.gen_uniform(n, 1 + reps, 10, 40)
-        elif kind == "g2":
-            _, c = oracle.cost_build(rng.integers(0, 10 * n, n), rng.integers(0, 10 * n, n), None, 250000, -1)
+        elif kind in ("g2", "g2u"):
+            _, c = oracle.cost_build(rng.integers(0, 10 * n, n - (2 if kind == "g2u" else 0)), rng.integers(0, 10 * n, n), None, 250000, -1)
+        elif kind == "wide":
+            c = rng.integers(0, 10**6, (n, n)).astype(np.int32)
+            t0 = time.perf_counter()   # (resident matrix on the GPU side too: the solve alone is timed)
+        elif kind == "geo2":
+            ax, ay, bx, by = (rng.integers(0, 4000, n) for _ in range(4))
+            c = (np.abs(ax[:, None] - bx[None, :]) + np.abs(ay[:, None] - by[None, :])).astype(np.int32)
+            t0 = time.perf_counter()
         else:
             _, c = oracle.cost_build(rng.integers(0, 50, n), rng.integers(0, 50, max(1, int(0.363 * n))), None,
                                      250000, 10)
@@ -402,7 +409,58 @@ def cpu_baseline(kind, n_gpu, seconds):
             "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "last_total": int(tot)}
 
 
-TRAFFIC_PROFILE = os.path.join("profiles", "r3", "rocprof_summary_r3_g1.json")   # the committed PMC summary the traffic figure is read from
+def glpk_baseline(sizes=(20, 100, 400)):
+    """the reference's own Python / GLPK path on this box's host — iff `cvxopt` imports here.  The build's
+    restatement of solver.py:13-26 (n x n objective as a cvxopt matrix, dense 2n x n^2 equality matrix A, one dummy
+    inequality, every variable binary, cvxopt.glpk.ilp) on perf.jl-style instances, one thread; N <= 400 because A is
+    O(N^3) bytes (1 GB at 400).  Returns a dict per N, or a string saying why it was not run."""
+    try:
+        from cvxopt import matrix
+        from cvxopt.glpk import ilp
+    except Exception as e:   # noqa: BLE001  (not installed in this image: no network, no wheel)
+        return "cvxopt not importable on this box (%s: %s); the stand-in C port is the CPU leg" % (type(e).__name__, str(e)[:80])
+    out = {}
+    rng = np.random.default_rng(1)
+    for n in sizes:
+        cost = rng.integers(10, 41, (n, n)).tolist()
+        t0 = time.perf_counter()
+        c = matrix(cost, tc="d")                     # solver.py:13 (inner lists are columns: index n*cab + cust)
+        a = np.zeros((2 * n, n * n))                 # solver.py:15-19
+        for i in range(n):
+            for j in range(n):
+                a[i][n * i + j] = 1.0
+                a[n + i][n * j + i] = 1.0
+        A = matrix(a)                                # solver.py:20
+        g = matrix([[0.0] * (n * n)])                # solver.py:21-23: one dummy inequality 0 x <= 0
+        h = matrix([0.0])
+        b = matrix([1.0] * (2 * n))
+        idx = set(range(n * n))                      # solver.py:24-25: all binary
+        status, x = ilp(matrix(list(c), (n * n, 1)), g.T, h, A, b, idx, idx)   # solver.py:26
+        dt = time.perf_counter() - t0
+        tot = None if x is None else int(round(sum(cost[k // n][k % n] * x[k] for k in range(n * n))))
+        out["n%d" % n] = {"seconds": dt, "assignments_per_s": n / dt, "status": status, "total": tot}
+    return out
+
+
+TRAFFIC_PROFILE = os.path.join("profiles", "r4", "rocprof_summary_r4_g1.json")   # the committed PMC summary the traffic figure is read from
+LIB_PATH = os.path.join(ROOT, "taxidispatcher_amd", "libtaxidispatcher_amd.so")
+
+
+def sha16(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def traffic_binary():
+    """sha-16 of the library the committed PMC summary was taken with (written by tools/summarize_profile.py)"""
+    try:
+        return json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE))).get("library_sha16")
+    except Exception:   # noqa: BLE001
+        return None
+
 
 
 def pmc_traffic(kernel_class):
@@ -538,8 +596,17 @@ def main():
             achieved = b / (p["avg_us"] * 1e-6) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom), "traffic_source": TRAFFIC_PROFILE,
+                    # the traffic figure comes from a committed rocprofv3 PMC pass, not from this run: the summary names the
+                    # library it was taken with, this run names the one it loaded
+                    "traffic_binary_sha16": traffic_binary(), "binary_sha16": sha16(LIB_PATH),
+                    "traffic_binary_matches": traffic_binary() is not None and traffic_binary() == sha16(LIB_PATH),
                     "algorithmic_bytes_per_launch": b, "avg_launch_us": p["avg_us"], "launches_per_step": p["launches"],
                     "largest_class_by_time": max(prof, key=lambda k: prof[k]["total_ms"])}
+            if args.workload == "tick":
+                # a 1300 x 1300 model is ~45 launches of a few microseconds each: launch / memory LATENCY bounds the step,
+                # an HBM fraction of it says nothing
+                roof.update({"bound": "latency", "note": "latency-bound: the largest streaming kernel moves %.1f MB per launch; "
+                             "frac is reported for the contract's sake only" % (b / 1e6)})
         line = {
             "metric": "NxN assignments/sec", "value": value, "unit": "assignments/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -635,6 +702,9 @@ def main():
                 extras[name] = {"ms_per_step": e_ms, "assignments_per_s": w2.n / (e_ms * 1e-3), "solver_stats": td.last_stats()}
                 del w2
                 torch.cuda.empty_cache()
+                if not args.no_cpu_baseline and not name.endswith("general_solver"):
+                    # the stand-in C port on a bounded sample of the same family (N <= 2048, ~2 s), same run, one host core
+                    extras[name]["cpu_baseline"] = cpu_baseline(kind, en, min(2.0, args.cpu_seconds))
             except Exception as e:
                 extras[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         td.set_line_metric(True)
@@ -647,6 +717,7 @@ def main():
         line["other_workloads"] = extras
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.workload, n, args.cpu_seconds)
+        line["cpu_baseline"]["glpk"] = glpk_baseline()   # solver.py's own path, iff cvxopt imports here
         if args.workload == "tick":   # same instance (seed 1) through the C port: the totals must agree
             line["total_matches_cpu_port"] = bool(int(total) == int(line["cpu_baseline"]["last_total"]))
     if dist.is_initialized():

@@ -187,6 +187,11 @@ __global__ __launch_bounds__(256) void k_hop_esc(int nrows, int nchunks, int rpb
 // ---- two hops: per free row the table row tab[b] = smallest r' (global id) with col(r') tight for the row and free
 // column b tight for r'.  window_zero = 1: only the block's column slice is read and "tight" means a zero cell at
 // price 0 (phase A); 0: the whole row, tight against the row's minimum of c + p.
+// The row is taken in segments of 256 chunks (one per thread): the tight cells of a segment go to a list in LDS first
+// (a thread-private walk over its 16 cells with three dependent loads behind every hit cost 16 serialised load chains
+// per wave: 19 us for a 2048-column slice), then all 256 threads take list entries — owner, escape masks, atomicMin into
+// the table row.  A segment holds at most 256 * E candidates: the list cannot overflow, the result does not depend on
+// the order of the appends.
 template <typename CT>
 __global__ __launch_bounds__(256) void k_hop_table(int n, int nrows, int row0, int nchunks, int rpb, int ncols_blk, int col_lo,
                                                    int max_rows, int window_zero, const CT *__restrict__ cc,
@@ -198,6 +203,8 @@ __global__ __launch_bounds__(256) void k_hop_table(int n, int nrows, int row0, i
     using PT = typename Tr<CT>::PT;
     constexpr int E = Tr<CT>::E;
     __shared__ int s_tab[HOP_FMAX];
+    __shared__ int s_cand[256 * E];
+    __shared__ int s_ncand;
     __shared__ long long s_v[4];
     if (ctl[CTL_FLAG]) return;
     const int lb = blockIdx.x / HOP_FMAX, a = blockIdx.x % HOP_FMAX;
@@ -208,6 +215,7 @@ __global__ __launch_bounds__(256) void k_hop_table(int n, int nrows, int row0, i
     const size_t pitch = (size_t)nchunks * E;
     const CT *rp = cc + (size_t)lrow * pitch;
     if (tid < HOP_FMAX) s_tab[tid] = INT_MAX;
+    if (tid == 0) s_ncand = 0;
     // the row's columns in question: its block's slice (phase A) or all of them
     const int ch_lo = window_zero ? (col_lo + lb * ncols_blk) / E : 0;
     const int ch_n = window_zero ? (ncols_blk + E - 1) / E : nchunks;
@@ -217,11 +225,22 @@ __global__ __launch_bounds__(256) void k_hop_table(int n, int nrows, int row0, i
         for (int t = tid; t < ch_n; t += 256) {
             uint32_t c[E];
             unpack<CT>(*reinterpret_cast<const uint4 *>(rp + (size_t)(ch_lo + t) * E), c);
+            PT pv[E];
+            const int j0 = (ch_lo + t) * E;
+            if constexpr (sizeof(PT) == 4) {
+                const int4 *pp = reinterpret_cast<const int4 *>(pk + j0);
 #pragma unroll
-            for (int e = 0; e < E; e++) {
-                const int j = (ch_lo + t) * E + e;
-                if (j < n) mv = min(mv, (long long)c[e] + (long long)(pk[j] >> 1));
+                for (int q = 0; q < E / 4; q++) {
+                    const int4 x = pp[q];
+                    pv[4 * q + 0] = x.x, pv[4 * q + 1] = x.y, pv[4 * q + 2] = x.z, pv[4 * q + 3] = x.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; e++) pv[e] = pk[j0 + e];
             }
+#pragma unroll
+            for (int e = 0; e < E; e++)
+                if (j0 + e < n) mv = min(mv, (long long)c[e] + (long long)(pv[e] >> 1));
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -231,19 +250,42 @@ __global__ __launch_bounds__(256) void k_hop_table(int n, int nrows, int row0, i
         if (lane == 0) s_v[w] = mv;
         __syncthreads();
         v = min(min(s_v[0], s_v[1]), min(s_v[2], s_v[3]));
-    } else
-        __syncthreads();
-    for (int t = tid; t < ch_n; t += 256) {
-        uint32_t c[E];
-        unpack<CT>(*reinterpret_cast<const uint4 *>(rp + (size_t)(ch_lo + t) * E), c);
+    }
+    __syncthreads();
+    for (int t0 = 0; t0 < ch_n; t0 += 256) {
+        const int t = t0 + tid;
+        if (t < ch_n) {
+            const uint4 raw = *reinterpret_cast<const uint4 *>(rp + (size_t)(ch_lo + t) * E);
+            bool any = true;
+            if constexpr (sizeof(CT) == 1 && std::is_same<CT, uint8_t>::value)   // (a zero cell is a zero byte)
+                if (window_zero) any = (zs_zero_bytes(raw.x) | zs_zero_bytes(raw.y) | zs_zero_bytes(raw.z) | zs_zero_bytes(raw.w)) != 0;
+            if (any) {
+                uint32_t c[E];
+                unpack<CT>(raw, c);
+                PT pv[E];
+                const int j0 = (ch_lo + t) * E;
+                if constexpr (sizeof(PT) == 4) {
+                    const int4 *pp = reinterpret_cast<const int4 *>(pk + j0);
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int j = (ch_lo + t) * E + e;
-            if (j >= n) continue;
-            if (window_zero && c[e] != 0) continue;
-            const long long val = (long long)c[e] + (long long)(pk[j] >> 1);
-            if (val != v) continue;
-            const int r = owner[j];
+                    for (int q = 0; q < E / 4; q++) {
+                        const int4 x = pp[q];
+                        pv[4 * q + 0] = x.x, pv[4 * q + 1] = x.y, pv[4 * q + 2] = x.z, pv[4 * q + 3] = x.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; e++) pv[e] = pk[j0 + e];
+                }
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const bool tight = j0 + e < n && (long long)c[e] + (long long)(pv[e] >> 1) == v && (!window_zero || c[e] == 0);
+                    if (tight) s_cand[atomicAdd(&s_ncand, 1)] = j0 + e;
+                }
+            }
+        }
+        __syncthreads();
+        const int nc = s_ncand;
+        for (int k = tid; k < nc; k += 256) {
+            const int r = owner[s_cand[k]];
             if (r < row0 || r >= row0 + nrows) continue;   // a free column (then the rounds take it), or a row of another shard
             if ((r - row0) / rpb != lb) continue;          // (two hops inside the block)
             unsigned long long m0 = esc[(size_t)(r - row0) * 2], m1 = esc[(size_t)(r - row0) * 2 + 1];
@@ -258,8 +300,10 @@ __global__ __launch_bounds__(256) void k_hop_table(int n, int nrows, int row0, i
                 atomicMin(&s_tab[b], r);
             }
         }
+        __syncthreads();
+        if (tid == 0) s_ncand = 0;
+        __syncthreads();
     }
-    __syncthreads();
     if (tid < HOP_FMAX) tab[((size_t)lb * HOP_FMAX + a) * HOP_FMAX + tid] = s_tab[tid] == INT_MAX ? -1 : s_tab[tid];
 }
 
@@ -273,7 +317,7 @@ __global__ __launch_bounds__(HOP_FMAX) void k_hop_match(int nrows, int row0, int
 {
     extern __shared__ uint32_t s_usedr[];   // one bit per row of the block
     __shared__ int s_usedc[HOP_FMAX];
-    __shared__ int s_key[2];
+    __shared__ int s_key[2][2];
     if (ctl[CTL_FLAG]) return;
     const int lb = blockIdx.x;
     const int nfr = hc->nfr[lb];
@@ -289,32 +333,38 @@ __global__ __launch_bounds__(HOP_FMAX) void k_hop_match(int nrows, int row0, int
     __syncthreads();
     const int *fr = frl + (size_t)lb * rpb, *fc = fcl + (size_t)lb * ncols_blk;
     const int blk_row0 = row0 + lb * rpb;
+    const int my_fc = tid < nc ? fc[tid] : 0;
     int done = 0;
+    // the table entry and the row id of the NEXT iteration are loaded while this one is decided (the loop is a chain of
+    // dependent global loads otherwise: ~1 us per row)
+    int r_nx = tid < nc ? tab[((size_t)lb * HOP_FMAX + 0) * HOP_FMAX + tid] : -1;
+    int i_nx = blk_row0 + fr[0];
     for (int a = 0; a < na; a++) {
-        const int i_g = blk_row0 + fr[a];
+        const int r = r_nx, i_g = i_nx;
+        if (a + 1 < na) {
+            r_nx = tid < nc ? tab[((size_t)lb * HOP_FMAX + a + 1) * HOP_FMAX + tid] : -1;
+            i_nx = blk_row0 + fr[a + 1];
+        }
         const uint32_t hsh = ((uint32_t)i_g + 1u) * 0x9E3779B1u;
         const int st = nc ? (int)(((uint64_t)(hsh ^ (hsh >> 15)) * (uint64_t)nc) >> 32) : 0;
-        int key = INT_MAX, r = -1;
-        if (tid < nc) {
-            r = tab[((size_t)lb * HOP_FMAX + a) * HOP_FMAX + tid];
-            if (r >= 0 && !s_usedc[tid]) {
-                const int rb = r - blk_row0;
-                if (!((s_usedr[rb >> 5] >> (rb & 31)) & 1u)) {
-                    int t = tid - st;
-                    t += t < 0 ? nc : 0;
-                    key = t;
-                }
+        int key = INT_MAX;
+        if (r >= 0 && !s_usedc[tid]) {
+            const int rb = r - blk_row0;
+            if (!((s_usedr[rb >> 5] >> (rb & 31)) & 1u)) {
+                int t = tid - st;
+                t += t < 0 ? nc : 0;
+                key = t;
             }
         }
         int best = key;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
-        if (lane == 0) s_key[w] = best;
+        if (lane == 0) s_key[a & 1][w] = best;
         __syncthreads();
-        best = min(s_key[0], s_key[1]);
+        best = min(s_key[a & 1][0], s_key[a & 1][1]);
         if (best != INT_MAX && key == best) {   // exactly one thread: the keys of a row are distinct
             const int rl = r - row0, il = i_g - row0;
-            const int j = r2c[rl], jp = col_lo + lb * ncols_blk + fc[tid];
+            const int j = r2c[rl], jp = col_lo + lb * ncols_blk + my_fc;
             r2c[il] = j;
             owner[j] = i_g;
             r2c[rl] = jp;

@@ -9,7 +9,11 @@ def short(name):
     i = name.find("(")
     return name[:i] if i > 0 else name
 
-res = {"kernel_stats": [], "pmc": {}}
+import hashlib
+_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "taxidispatcher_amd", "libtaxidispatcher_amd.so")
+res = {"kernel_stats": [], "pmc": {},
+       # the library these counters were taken with: bench.py prints the same hash of the library IT loaded next to the traffic figure
+       "library_sha16": hashlib.sha256(open(_lib, "rb").read()).hexdigest()[:16] if os.path.exists(_lib) else None}
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         res["kernel_stats"].append({"kernel": short(r["Name"]), "calls": int(r["Calls"]), "total_us": float(r["TotalDurationNs"]) / 1e3,
