@@ -205,6 +205,7 @@ long long g_np_plimit = NP_PLIMIT;   // TD_NP_PLIMIT  (tests) lower price limit 
 int g_fuse_t = 2;           // TD_FUSE_T        padded models (dummy requests): one fused transpose + compress pass, no void 1-byte attempt (2: as 1-byte cells + escape when they fit, 1: 4-byte cells, 0: off)
 int g_fuse_spec = 1;        // TD_FUSE_SPEC     the fused pass is speculative (flags read with the final result) when the probe saw a plausible fill value
 int g_fused_rounds = 8;      // TD_FUSED_ROUNDS  bidding rounds launched for a padded model taken by the fused pass
+int g_tick_rounds = 5;       // TD_TICK_ROUNDS   ... of td_tick's remainder (n < 2048): 5 rounds make progress on the bench tick, every further launch is ~4 us of nothing
 int g_forest = 1;           // TD_FOREST        cooperative incremental shortest-path forest (k_forest) as the finisher of 4-byte rows
 int g_forest_min_n = 2048;  // TD_FOREST_MIN_N  smallest n it is used for
 long long g_forest_w0 = 16; // TD_FOREST_W0     first label window
@@ -256,6 +257,7 @@ void read_tunables()
     if (const char *e = getenv("TD_FUSE_T")) g_fuse_t = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("TD_FUSE_SPEC")) g_fuse_spec = atoi(e) != 0;
     if (const char *e = getenv("TD_FUSED_ROUNDS")) g_fused_rounds = std::max(1, std::min(48, atoi(e)));
+    if (const char *e = getenv("TD_TICK_ROUNDS")) g_tick_rounds = std::max(1, std::min(48, atoi(e)));
     if (const char *e = getenv("TD_FOREST")) g_forest = atoi(e) != 0;
     if (const char *e = getenv("TD_FOREST_MIN_N")) g_forest_min_n = std::max(64, atoi(e));
     if (const char *e = getenv("TD_FOREST_W0")) g_forest_w0 = std::max(1ll, atoll(e));
@@ -2955,6 +2957,7 @@ struct td_shard {
     bool fused8 = false;       // ... as 1-byte cells with the escape code (u8e, bpc code 6)
     const long long *skip = nullptr;  // device flag of a pending line-metric probe: non-zero makes the compress pass a no-op
     // block-local start (td_blocks.h)
+    bool tick_sized = false;   // td_tick's remainder (hinted, n < 2048): the rounds leave a dozen rows, the serial workgroup is through before a speculative batch + its commit are — no read-back of the free-row count to decide that
     int zs_V = 0;              // diagonal blocks of the whole matrix the 1-byte attempt may start in (0: off)
     bool zs_done = false;      // the compress pass wrote the zero-slice bids of phase A's round 0: sv_phase_a is due
     bool state_ready = false;  // sharded solve: the state was initialised in front of the compress pass and phase A has run on it (td_shard_begin must not redo it)
@@ -3405,7 +3408,7 @@ int sv_finish_t(Solver &sv, const ShardTab &tab, int *r2c_full)
     // ---- speculative parallel searches first (a few batches), the serial workgroup mops up
     // (u8 instances go straight to the lean tie-batching serial workgroup, which is faster there)
     int nfree_left = -1;   // free rows the speculative batches left (-1: not read back)
-    if (g_psap_batches > 0 && CH <= 4 && CH * E <= 16 && lds && n >= 64 && !IsLean8<CT>::value) {
+    if (g_psap_batches > 0 && CH <= 4 && CH * E <= 16 && lds && n >= 64 && !IsLean8<CT>::value && !sv.tick_sized) {
         Ctx &c = ctx();
         using PT = typename Tr<CT>::PT;
         int rc = ensure(sv.psrec, sizeof(PsRec<PT>) * (size_t)PS_G);
@@ -3843,6 +3846,7 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     int64_t range_hint = -1;
     sv.defer_const = g_defer_const && !g_solver_eps;
     sv.bid0_done = false;
+    sv.tick_sized = false;
     int64_t hinted_range = -1;
     if (hinted_fuse) {   // the caller (td_tick) told the shape: the fused pass at once, speculatively (flags with the final read-back)
         bool ff = false;
@@ -3856,7 +3860,8 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         sv.fused_t = true;
         transposed = true;
         hinted_range = hint.fill;
-        max_rounds = std::min(max_rounds, g_fused_rounds);
+        max_rounds = std::min(max_rounds, n < 2048 ? std::min(g_fused_rounds, g_tick_rounds) : g_fused_rounds);
+        sv.tick_sized = n < 2048;
     }
 restart:
     for (int orient = 0; orient < 2 && !solved; orient++) {

@@ -74,6 +74,9 @@ void assign_hint_padded(int const_cols, int const_rows, int32_t fill);
 int lcm_hinted(int n, const int32_t *cost, int32_t mask, int32_t threshold, int stop_value_on, int32_t stop_value, int stop_size,
                int64_t sum_below, int max_pairs, int32_t *rows, int32_t *cols, int32_t *n_pairs, int64_t *total, int32_t *last_min,
                int hint_vmin, int hint_vmax);
+// td_core.hip: td_cost_build for device-resident library buffers, without the trailing stream synchronisation (td_tick)
+int cost_build_async(const int32_t *cab_to, int n_s, const int32_t *dem_from, int n_d, const int32_t *dist, int S, int32_t fill,
+                     int32_t threshold, int32_t *cost);
 void prof_begin(int k);
 void prof_end(int k);
 void prof_flush();

@@ -421,7 +421,7 @@ int td_last_stats(int64_t *out, int n)
 
 static int cost_build_impl(const int32_t *cab_to, const int32_t *cab_id, int n_s, const int32_t *dem_from,
                            const int32_t *dem_id, int n_d, const int32_t *dist, int S, int32_t fill, int32_t threshold,
-                           int by_id, int row0, int nrows, int32_t *cost)
+                           int by_id, int row0, int nrows, int32_t *cost, bool nosync = false)
 {
     TD_REQUIRE_INIT();
     Ctx &c = ctx();
@@ -503,9 +503,21 @@ static int cost_build_impl(const int32_t *cab_to, const int32_t *cab_id, int n_s
     if (!out_dev) {
         TD_HIP(hipMemcpyAsync(cost, d_cost, cbytes, hipMemcpyDeviceToHost, c.stream));
     }
-    TD_HIP(hipStreamSynchronize(c.stream));
+    if (!(nosync && out_dev)) TD_HIP(hipStreamSynchronize(c.stream));
     return TD_OK;
 }
+
+}   // extern "C"
+
+// td_tick's cost builds: every array is a library buffer on the device and the next kernel is queued on the same stream,
+// so the call returns without waiting (the public entry points wait: their callers may release the arrays at once)
+int td::cost_build_async(const int32_t *cab_to, int n_s, const int32_t *dem_from, int n_d, const int32_t *dist, int S, int32_t fill,
+                         int32_t threshold, int32_t *cost)
+{
+    return cost_build_impl(cab_to, nullptr, n_s, dem_from, nullptr, n_d, dist, S, fill, threshold, 0, 0, -1, cost, true);
+}
+
+extern "C" {
 
 int td_cost_build(const int32_t *cab_to, const int32_t *cab_id, int n_s, const int32_t *dem_from,
                   const int32_t *dem_id, int n_d, const int32_t *dist, int S, int32_t fill, int32_t threshold,

@@ -163,7 +163,7 @@ extern "C" int td_tick(const int32_t *cab_to, int n_s, const int32_t *dem_from, 
         d_dist = dd;
     }
     int32_t *d_a = (int32_t *)t.cost_a.p;
-    if ((rc = td_cost_build(d_cab, nullptr, n_s, d_dem, nullptr, n_d, d_dist, S, fill, threshold, 0, d_a))) return rc;
+    if ((rc = td::cost_build_async(d_cab, n_s, d_dem, n_d, d_dist, S, fill, threshold, d_a))) return rc;
     int k = 0;
     int64_t lcm_total = 0;
     int32_t last_min = fill;
@@ -199,7 +199,7 @@ extern "C" int td_tick(const int32_t *cab_to, int n_s, const int32_t *dem_from, 
     if (n2 > 0 && !(lcm_ran && last_min == fill)) {
         if ((rc = ensure(t.cost_b, sizeof(int32_t) * (size_t)n2 * n2))) return rc;
         int32_t *d_b = (int32_t *)t.cost_b.p;
-        if ((rc = td_cost_build(d_cab2, nullptr, kc, d_dem2, nullptr, kd, d_dist, S, fill, threshold, 0, d_b))) return rc;
+        if ((rc = td::cost_build_async(d_cab2, kc, d_dem2, kd, d_dist, S, fill, threshold, d_b))) return rc;
         td::assign_hint_padded(n2 - kd, n2 - kc, fill);   // dummy requests / dummy cabs of the remainder: no probe, no 1-byte attempt
         if ((rc = td_assign(n2, d_b, row_to_col, total, nullptr))) return rc;   // ends with a stream synchronisation
     } else {
