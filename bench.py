@@ -17,9 +17,11 @@ workload : g1  perf.jl:5 instance family, cost ~ U{10..40}, N = 16384 (BASELINE 
 --gpus N : one process per GPU (torch.distributed, RCCL).  Started without WORLD_SIZE, bench.py
            launches the N ranks itself (torch.distributed.run as a child process, before anything
            touches the GPU).  For N > 1 the headline is BASELINE configs[3]: ONE 65 536 x 65 536
-           instance, rows sharded over the N GPUs, every rank builds its row block in place, one
-           RCCL MAX all-reduce of the packed bid keys per bidding round ("scaling": "strong"; the
-           same instance solved by td_assign on one GPU is timed in the same run).  The replicas
+           instance, rows sharded over the N GPUs, every rank builds its row block in place and
+           starts on its own diagonal blocks (csrc/td_blocks.h), ONE RCCL all-gather, then one
+           RCCL MAX all-reduce of the packed bid keys per bidding round for the rows still free
+           ("scaling": "strong"; the same instance solved by td_assign on one GPU is timed in the
+           same run).  The replicas
            figure (an independent N = 16 384 instance per GPU, no collective, weak scaling) is a
            side field; --multi-mode replicas makes it the headline instead.
 
@@ -193,13 +195,17 @@ def sharded_leg(n, world, rank, torch, dist, ffi, steps, warmup, builder="gen"):
         cab = torch.from_numpy(rng.integers(0, S, n).astype(np.int32)).cuda()
         dem = torch.from_numpy(rng.integers(0, S, n).astype(np.int32)).cuda()
 
+    seq = {}
+
     def step():
         if nrows and builder == "cost":
             ffi.check(ffi.lib().td_cost_build_rows(cab.data_ptr(), None, n, dem.data_ptr(), None, n, table.data_ptr(), S, 250000, -1, 0,
                                                    row0, nrows, rows.data_ptr()))
         elif nrows:
             ffi.check(ffi.lib().td_gen_uniform(n, 7, 10, 40, row0, nrows, rows.data_ptr()))
-        return sharded.solve_sharded(sh, dist)[1]
+        tot = sharded.solve_sharded(sh, dist)[1]
+        seq["path"], seq["left"] = sharded.solve_sharded.last_path, getattr(sharded.solve_sharded, "last_left", None)
+        return tot
 
     def barrier():
         torch.cuda.synchronize()
@@ -224,9 +230,14 @@ def sharded_leg(n, world, rank, torch, dist, ffi, steps, warmup, builder="gen"):
         sh.close()
     del rows
     torch.cuda.empty_cache()
-    return {"workload": "g1 N=%d, ONE instance row-sharded over %d GPUs (%d rows each), shard-local %s + "
-                        "RCCL MAX all-reduce of %d KiB keys per bidding round, finisher on rank 0 over hipIpc-mapped "
-                        "shards" % (n, world, nrows, "cost build (td_cost_build_rows, 1000-stand table)" if builder == "cost" else "cost write", n * 8 // 1024),
+    how = ("block-local start on every rank's diagonal blocks (csrc/td_blocks.h), ONE all-gather of %d KiB, %s"
+           % ((16 + 2 * nrows) * 4 * world // 1024, "nothing left for the rounds" if seq.get("left") == 0 else
+              "then RCCL MAX all-reduces of %d KiB keys per bidding round + finisher on rank 0 for the %s rows left" % (n * 8 // 1024, seq.get("left")))
+           if seq.get("path") == "blocks" else
+           "RCCL MAX all-reduce of %d KiB keys per bidding round, finisher on rank 0 over hipIpc-mapped shards" % (n * 8 // 1024))
+    return {"workload": "g1 N=%d, ONE instance row-sharded over %d GPUs (%d rows each), shard-local %s + %s"
+                        % (n, world, nrows, "cost build (td_cost_build_rows, 1000-stand table)" if builder == "cost" else "cost write", how),
+            "sequence": seq.get("path"), "rows_left_after_phase_a": seq.get("left"),
             "n": n, "ms_per_step": 1e3 * dt / steps, "assignments_per_s": n * steps / dt,
             "total_cost": int(total), "optimal": bool(total == 10 * n), "scaling": "strong", "seconds": dt}
 
@@ -630,7 +641,8 @@ def main():
                 line.update({"value": shard_res["assignments_per_s"], "ms_per_step": shard_res["ms_per_step"],
                              "scaling": "strong",
                              "config": {"workload": shard_res["workload"], "n": sn, "instances_per_step": 1,
-                                        "parallelism": "rows sharded over %d GPUs, RCCL MAX all-reduce per bidding round" % world},
+                                        "parallelism": "rows sharded over %d GPUs; block-local start + one RCCL all-gather, RCCL MAX all-reduce per "
+                                                       "bidding round for what is left" % world},
                              "pairs_per_s": float(sn) * sn * 1e3 / shard_res["ms_per_step"],
                              "whole_step_algorithmic_GBps": 8.0 * sn * sn / (shard_res["ms_per_step"] * 1e-3) / 1e9,
                              "total_cost": shard_res["total_cost"]})

@@ -153,7 +153,8 @@ enum {
     CTL_TIED = CTL_WORDS + 7,    // rows whose two smallest costs are equal (bidding round 0, every 16th row sampled)   // a speculative batch committed nothing: later batches of the group exit at once
     CTL_FOREST = CTL_WORDS + 8,  // levels of the incremental forest finisher (0: another finisher ran)
     CTL_RSEEN = CTL_WORDS + 10,  // [+10..11] 64-bit largest row range seen by the row-wise compress passes (whether it fits or not)
-    CTL_ALL = CTL_WORDS + 12
+    CTL_COREMISS = CTL_WORDS + 12,  // warm start on the sparse core: [+0] bidders whose list did not prove their best column (they bid on the dense row), [+1] bidders seen, [+2..3] 64-bit smallest price of any column
+    CTL_ALL = CTL_WORDS + 16
 };
 
 constexpr int ROW_BITS = 20;
@@ -217,6 +218,12 @@ int g_hop_passes = 2;       // TD_HOP_PASSES    two-hop passes at the end of pha
 int g_hop_max_rows = HOP_FMAX;   // TD_HOP_MAX_ROWS  a block with more free rows than this is left to the rounds
 int g_hop_global = 1;       // TD_HOP_GLOBAL    td_assign: one two-hop pass over the whole matrix after phase A
 int g_zs_global_rounds = 6; // TD_ZS_GLOBAL_ROUNDS  td_assign: bidding rounds launched for what the block-local start left
+int g_core = 1;             // TD_CORE          the warm start's eps-phases bid on a sparse core of every row (td_core_warm.h)
+int g_core_k = 64;          // TD_CORE_K        rank of the group minimum that becomes a row's threshold (about 256 * -ln(1 - k/256) cells per row: 74)
+int g_core_min_n = 8192;    // TD_CORE_MIN_N    smallest n it is used for (uniform 0..10^6: n = 4096 9.1 -> 11.4 ms, the dense rounds of 16 KiB rows are cheaper than building the lists; n = 16 384 43.7 -> 32.3 ms)
+int g_core_mode = 1;        // TD_CORE_MODE     1: the lists are taken on trust in the phases whose eps is at most TD_CORE_EPS x their average reach (the earlier phases bid on the dense rows); 0: every phase, a bid only where the list proves the row's best column, the other bidders on their dense rows
+double g_core_eps = 1.0;    // TD_CORE_EPS
+int g_core_patience = 6;    // TD_CORE_PATIENCE groups of 8 rounds a phase on trusted lists may take before the lists are dropped for good
 int g_solver_eps = 0;       // TD_SOLVER=eps    literal eps-scaling auction (comparison mode)
 int g_eps_theta = 8;        // TD_EPS_THETA
 long long g_eps0_mult = 4;  // TD_EPS0_MULT     eps0 = (n+1) * mult ; 0 = start at eps = 1
@@ -276,6 +283,12 @@ void read_tunables()
     if (const char *e = getenv("TD_LINE")) g_line = atoi(e) != 0;
     if (const char *e = getenv("TD_LINE_MIN_N")) g_line_min_n = std::max(2, atoi(e));
     if (const char *e = getenv("TD_PSAP8_GRID")) g_psap8_grid = std::max(1, std::min(192, atoi(e)));
+    if (const char *e = getenv("TD_CORE")) g_core = atoi(e) != 0;
+    if (const char *e = getenv("TD_CORE_K")) g_core_k = std::max(2, std::min(200, atoi(e)));
+    if (const char *e = getenv("TD_CORE_MIN_N")) g_core_min_n = std::max(256, atoi(e));
+    if (const char *e = getenv("TD_CORE_MODE")) g_core_mode = atoi(e);
+    if (const char *e = getenv("TD_CORE_EPS")) g_core_eps = atof(e);
+    if (const char *e = getenv("TD_CORE_PATIENCE")) g_core_patience = std::max(1, atoi(e));
     if (const char *e = getenv("TD_BLOCKS")) g_blocks = std::max(-1, std::min(HOP_BMAX, atoi(e)));
     if (const char *e = getenv("TD_BLOCKS_MIN_N")) g_blocks_min_n = std::max(0, atoi(e));
     if (const char *e = getenv("TD_ZS_ROUNDS")) g_zs_rounds = std::max(0, std::min(32, atoi(e)));
@@ -688,7 +701,8 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nrows, int
                                                           unsigned long long *__restrict__ bid,
                                                           const int *__restrict__ ctl, int round, int tie_evict,
                                                           long long kscale = 1, long long eps = 0,
-                                                          int *__restrict__ tied = nullptr /* round 0: count rows tied at their minimum */)
+                                                          int *__restrict__ tied = nullptr /* round 0: count rows tied at their minimum */,
+                                                          const uint8_t *__restrict__ only = nullptr /* non-null: only the rows flagged here bid (td_core_warm.h) */)
 {
     using PT = typename Tr<CT>::PT;
     constexpr int E = Tr<CT>::E;
@@ -708,6 +722,7 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nrows, int
     }
     for (int lrow = blockIdx.x * nw + w; lrow < nrows; lrow += gridDim.x * nw) {
         if (r2c[lrow] != -1) continue;   // assigned, or a deferred constant row
+        if (only && !only[lrow]) continue;
         const int row = row0 + lrow;  // global row id (shards own rows [row0, row0+nrows))
         const CT *rp = cc + (size_t)lrow * pitch;
         // Start chunk of the rotated scan.  It spreads the tie-breaks of different rows over the
@@ -1024,6 +1039,7 @@ __global__ __launch_bounds__(1024) void k_freelist(int n, const int *__restrict_
 }
 
 #include "td_blocks.h"
+#include "td_core_warm.h"
 
 // Constant rows (every cell equal: dummy rows of a padded rectangular model, cabs with no request
 // in range) cost the same in any column, so they sit out the bidding and the searches and take
@@ -2962,9 +2978,10 @@ struct td_shard {
     bool zs_done = false;      // the compress pass wrote the zero-slice bids of phase A's round 0: sv_phase_a is due
     bool state_ready = false;  // sharded solve: the state was initialised in front of the compress pass and phase A has run on it (td_shard_begin must not redo it)
     Buf ob, esc, hop, hoptab;  // owned bytes per column, escape masks per row, HopCtl, the two-hop tables
+    Buf core, core_n, core_t, core_need;   // sparse core of the warm start (td_core_warm.h): lists, their lengths, the smallest value outside, the rows that need their dense row
     void free_all()
     {
-        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &rconst, &misc, &psrec, &tbuf, &xbuf, &fbuf, &cmask, &ob, &esc, &hop, &hoptab};
+        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &rconst, &misc, &psrec, &tbuf, &xbuf, &fbuf, &cmask, &ob, &esc, &hop, &hoptab, &core, &core_n, &core_t, &core_need};
         for (Buf *b : bs) {
             if (b->p) (void)hipFree(b->p);
             b->p = nullptr;
@@ -3684,31 +3701,94 @@ int sv_warm_t(Solver &sv, int64_t range, int64_t *rounds_out)
     int64_t rounds = 0;
     bool first = true;
     ProfScope ps(TD_K_BID);
+    // the phases bid on a sparse core of every row (td_core_warm.h): 8 MB instead of 1 GiB per full round at n = 16 384
+    bool use_core = g_core && sizeof(CT) == 4 && n >= g_core_min_n && sv.nrows == n;
+    bool dense_too = true;   // rows whose list does not prove their best column bid on the dense row (skipped while a group of rounds flags nobody)
+    int64_t core_rounds = 0, miss_total = 0, bids_total = 0;
+    bool phase_core = true;
+    double t_avg = 0.0;
+    if (use_core) {
+        int rc;
+        if ((rc = ensure(sv.core, sizeof(uint2) * (size_t)n * CORE_CAP))) return rc;
+        if ((rc = ensure(sv.core_n, sizeof(int) * (size_t)n))) return rc;
+        if ((rc = ensure(sv.core_t, sizeof(uint32_t) * (size_t)n))) return rc;
+        if ((rc = ensure(sv.core_need, (size_t)n + 64))) return rc;
+        TD_HIP(hipMemsetAsync(sv.core_need.p, 0, (size_t)n, c.stream));
+        unsigned long long *t_sum = (unsigned long long *)((char *)sv.misc.p + 2048 + 64);
+        TD_HIP(hipMemsetAsync(t_sum, 0, sizeof(unsigned long long), c.stream));
+        k_core_build<CT><<<std::min(n, c.n_cu * 8), 256, 0, c.stream>>>(n, n, sv.nchunks, g_core_k, (const CT *)sv.cc.p, (uint2 *)sv.core.p,
+                                                                       (int *)sv.core_n.p, (uint32_t *)sv.core_t.p, t_sum);
+        TD_HIP(hipGetLastError());
+        if (g_core_mode == 1) {
+            TD_HIP(hipMemcpyAsync(c.pinned, t_sum, sizeof(unsigned long long), hipMemcpyDeviceToHost, c.stream));
+            TD_HIP(hipStreamSynchronize(c.stream));
+            t_avg = (double)(((unsigned long long *)c.pinned)[0]) / (double)n;
+        }
+    }
     for (long long eps = std::max<long long>(1, range / g_warm_div);; eps = std::max<long long>(eps_last, eps / g_warm_theta)) {
         (void)first;
         k_eps_reset<PT><<<(std::max(n, (int)CTL_WORDS) + 255) / 256, 256, 0, c.stream>>>(n, sv.nrows, (PT *)sv.price.p, (int *)sv.owner.p,
                                                                                            (int *)sv.r2c.p, (int *)sv.misc.p);
         first = false;
+        const bool trust = use_core && g_core_mode == 1;
+        if (trust) phase_core = (double)eps <= g_core_eps * t_avg;
         for (int grp = 0; grp < g_warm_groups; grp++) {
             for (int r = 0; r < 8; r++) {
-                k_bid<CT, false, true><<<(sv.nrows + 3) / 4, 256, 0, c.stream>>>(n, sv.nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p,
-                                                                               (const PT *)sv.price.p, (const int *)sv.r2c.p, keys,
-                                                                               (const int *)sv.misc.p, 60, 1, 1, eps);
+                if (use_core && phase_core) {
+                    k_bid_core<PT><<<(sv.nrows + 3) / 4, 256, 0, c.stream>>>(n, sv.nrows, sv.row0, (const uint2 *)sv.core.p, (const int *)sv.core_n.p,
+                                                                            (const uint32_t *)sv.core_t.p, (const PT *)sv.price.p,
+                                                                            (const int *)sv.r2c.p, keys, (int *)sv.misc.p, eps,
+                                                                            trust ? nullptr : (uint8_t *)sv.core_need.p);
+                    if (dense_too && !trust)
+                        k_bid<CT, false, true><<<(sv.nrows + 3) / 4, 256, 0, c.stream>>>(n, sv.nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p,
+                                                                                       (const PT *)sv.price.p, (const int *)sv.r2c.p, keys,
+                                                                                       (const int *)sv.misc.p, 60, 1, 1, eps, nullptr,
+                                                                                       (const uint8_t *)sv.core_need.p);
+                    core_rounds++;
+                } else
+                    k_bid<CT, false, true><<<(sv.nrows + 3) / 4, 256, 0, c.stream>>>(n, sv.nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p,
+                                                                                   (const PT *)sv.price.p, (const int *)sv.r2c.p, keys,
+                                                                                   (const int *)sv.misc.p, 60, 1, 1, eps);
                 k_assign<PT><<<(n + 255) / 256, 256, 0, c.stream>>>(n, sv.nrows, sv.row0, keys, (PT *)sv.price.p, (int *)sv.owner.p,
                                                                    (int *)sv.r2c.p, (int *)sv.misc.p, 60, IsNP<CT>::value ? g_np_plimit : 0ll);
             }
             rounds += 8;
             k_freelist<<<1, 1024, 0, c.stream>>>(n, (const int *)sv.r2c.p, (int *)sv.list.p, (int *)sv.misc.p);
             TD_HIP(hipMemcpyAsync(c.pinned, (int *)sv.misc.p + CTL_NFREE, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+            if (use_core && phase_core && !trust) {
+                TD_HIP(hipMemcpyAsync((int *)c.pinned + 1, (int *)sv.misc.p + CTL_COREMISS, 2 * sizeof(int), hipMemcpyDeviceToHost, c.stream));
+                TD_HIP(hipMemsetAsync((int *)sv.misc.p + CTL_COREMISS, 0, 2 * sizeof(int), c.stream));
+                k_price_min<PT><<<1, 1024, 0, c.stream>>>(n, (const PT *)sv.price.p, (int *)sv.misc.p);
+            }
             TD_HIP(hipStreamSynchronize(c.stream));
+            if (use_core && phase_core && !trust) {
+                const int miss = ((int *)c.pinned)[1], bids = ((int *)c.pinned)[2];   // flagged bidders / all bidders of this group's 8 rounds
+                miss_total += miss;
+                bids_total += bids;
+                dense_too = miss > 0;
+                // most of the bidders outgrew their lists — every early phase (eps far above the lists' thresholds: price
+                // differences, not costs, decide the bids) and geometric rows in crowded regions: the lists only add a launch
+                // per round; the next phase tries them again
+                if (phase_core && (long long)miss * 2 > (long long)bids) phase_core = false;
+            }
             if (((int *)c.pinned)[0] <= (g_warm_cut > 0 ? n / g_warm_cut : 0)) break;
+            // a phase on trusted lists that is not through after TD_CORE_PATIENCE groups: the lists do not hold the columns the
+            // rows need (|a - b| with the recogniser off: rows of a crowded stretch need partners hundreds of ranks away and
+            // their lists inflate the prices of the stretch instead) — the dense rows from here on, for good
+            if (trust && phase_core && grp + 1 >= g_core_patience) {
+                phase_core = false;
+                use_core = false;
+            }
         }
+        if (use_core && !trust) dense_too = true, phase_core = true;   // a new phase: every row is free again
         if (eps <= eps_last) break;
     }
     // only the prices are kept
     k_eps_reset<PT><<<(std::max(n, (int)CTL_WORDS) + 255) / 256, 256, 0, c.stream>>>(n, sv.nrows, (PT *)sv.price.p, (int *)sv.owner.p,
                                                                                    (int *)sv.r2c.p, (int *)sv.misc.p);
     TD_HIP(hipGetLastError());
+    if (getenv("TD_DEBUG")) fprintf(stderr, "[td] warm start: %lld rounds, %lld of them on the sparse core (mode %d, average reach of the lists %.0f), %lld of %lld bidders took their dense row\n",
+                                    (long long)rounds, (long long)core_rounds, g_core_mode, t_avg, (long long)miss_total, (long long)bids_total);
     *rounds_out = rounds;
     return TD_OK;
 }

@@ -301,6 +301,36 @@ def test_bench_sharded_leg_through_rccl(td):
     assert sh["optimal"] and sh["total_cost"] == 10 * 8192 and sh["speedup_vs_single_gpu"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_two_gpus_end_to_end(td):
+    """the first box that shows more than one GPU runs `bench.py --gpus 2` end to end — two ranks, RCCL with
+    world 2 (the all-gather of the block-local start, the scalar all-reduces, the MAX all-reduces of the bid keys should rows
+    be left), hipIpc peer mappings between two different devices if the finisher is needed.  Skipped on one-GPU boxes."""
+    import json
+    import subprocess
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-extras", "--sharded-n", "16384", "--n", "8192"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    sh = line["sharded_single_instance"]
+    assert "error" not in sh, sh
+    assert sh["optimal"] and sh["total_cost"] == 10 * 16384 and sh["speedup_vs_single_gpu"] > 0
+    assert sh["sequence"] in ("blocks", "auction")
+    # the plain sequence too (a MAX all-reduce of the keys per round, the finisher on rank 0 over hipIpc-mapped shards)
+    env["TD_SHARD_BLOCKS"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-extras", "--sharded-n", "16384", "--n", "8192"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    sh = json.loads(r.stdout.strip().splitlines()[-1])["sharded_single_instance"]
+    assert "error" not in sh and sh["optimal"] and sh["sequence"] == "auction", sh
+
+
 def _line_instance(n, seed, spread=10):
     rng = np.random.default_rng(seed)
     a, b = rng.integers(0, spread * n, n), rng.integers(0, spread * n, n)
