@@ -1321,6 +1321,96 @@ __global__ __launch_bounds__(256) void k_compress_tr8(int n, int npad, const int
     if (bad) atomicOr(&ctl[CTL_FLAG], 1);
 }
 
+// The same pass with WIDE tiles: 256 of the caller's columns x TR8W_ROWS rows per workgroup.  Wave w takes the column group
+// [64w, 64w + 64): one instruction of the four waves together reads 4 rows x 1 KiB CONTIGUOUS (the narrow tile read 256-byte
+// pieces at a 64 KiB stride: 3.8 TB/s of traffic), every transposed row leaves as TR8W_ROWS contiguous bytes.
+template <int TR8W_ROWS>
+__global__ __launch_bounds__(256) void k_compress_tr8w(int n, int npad, const int32_t *__restrict__ in, uint8_t *__restrict__ out, int base,
+                                                       int esc_raw, int *__restrict__ colmin, int *__restrict__ colmax, int *__restrict__ ctl)
+{
+    constexpr int LP = TR8W_ROWS + 4;
+    static_assert(TR8W_ROWS % 128 == 0 && TR8W_ROWS <= 256, "a transposed row leaves as TR8W_ROWS / 4 dwords: 32 or 64 lanes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char tb[];   // [256][LP]
+    __shared__ int s_mn[256], s_mx[256];
+    const int bx = blockIdx.x * 256, ry0 = blockIdx.y * TR8W_ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    s_mn[tid] = INT_MAX;
+    s_mx[tid] = INT_MIN;
+    __syncthreads();
+    const int cg = lane & 15, rs = lane >> 4;
+    int mn[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX}, mx[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+    bool bad = false;
+    const int lc0 = 64 * wv + 4 * cg;   // the lane's first column inside the tile
+    const int jc0 = bx + lc0;
+    const bool vec = (n % 4 == 0);
+    constexpr int U = 8;
+    for (int p0 = 0; p0 < TR8W_ROWS / 4; p0 += U) {
+        int4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int r = 4 * (p0 + u) + rs, i = ry0 + r;
+            if (i < n && vec && jc0 + 3 < n)
+                v[u] = *reinterpret_cast<const int4 *>(in + (int64_t)i * n + jc0);
+            else {
+                int t4[4];
+#pragma unroll
+                for (int x = 0; x < 4; x++) t4[x] = (i < n && jc0 + x < n) ? in[(int64_t)i * n + jc0 + x] : esc_raw;
+                v[u] = make_int4(t4[0], t4[1], t4[2], t4[3]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int r = 4 * (p0 + u) + rs, i = ry0 + r;
+            const int vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            uint32_t packed = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                uint32_t code = 0xFFu;
+                if (i < n && jc0 + x < n) {
+                    mn[x] = min(mn[x], vv[x]);
+                    mx[x] = max(mx[x], vv[x]);
+                    const int d = vv[x] - base;
+                    if (vv[x] == esc_raw)
+                        code = U8E_ESC;
+                    else {
+                        code = (uint32_t)d & 0xFFu;
+                        bad = bad || d < 0 || d > 253;
+                    }
+                }
+                packed |= code << (8 * x);
+            }
+            // 4 x 4 transpose over the lanes cg + 16 * q (rows 4(p0+u) + q): my dword = the four rows of column lc0 + rs
+            uint32_t mine = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t pq = (uint32_t)__shfl((int)packed, cg + 16 * q);
+                mine |= ((pq >> (8 * rs)) & 0xFFu) << (8 * q);
+            }
+            *reinterpret_cast<uint32_t *>(tb + (size_t)(lc0 + rs) * LP + 4 * (p0 + u)) = mine;
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+        if (mn[x] <= mx[x]) {
+            atomicMin(&s_mn[lc0 + x], mn[x]);
+            atomicMax(&s_mx[lc0 + x], mx[x]);
+        }
+    __syncthreads();
+    // wave wv writes the transposed rows 64 wv .. + 63, 64 / (TR8W_ROWS / 4) of them per instruction
+    constexpr int DW = TR8W_ROWS / 4, RPI = 64 / DW;
+    for (int k = 0; k < 64; k += RPI) {
+        const int rr = wv * 64 + k + lane / DW, jj = bx + rr;
+        const int dw = lane % DW, b = ry0 + 4 * dw;
+        if (jj < n && b < npad)
+            *reinterpret_cast<uint32_t *>(out + (size_t)jj * npad + b) = *reinterpret_cast<const uint32_t *>(tb + (size_t)rr * LP + 4 * dw);
+    }
+    if (bx + tid < n && s_mn[tid] <= s_mx[tid]) {
+        atomicMin(&colmin[bx + tid], s_mn[tid]);
+        atomicMax(&colmax[bx + tid], s_mx[tid]);
+    }
+    if (bad) atomicOr(&ctl[CTL_FLAG], 1);
+}
+
 __global__ void k_tr_finish(int n, int base, const int *__restrict__ colmin, const int *__restrict__ colmax, int32_t *__restrict__ rowmin,
                             int *__restrict__ rconst, int *__restrict__ ctl, int esc_raw = 0, int with_esc = 0,
                             long long assumed_range = -1 /* >= 0: the speculative pass went on as if every cell were <= base + this (32-bit prices, BIG = 2^28): a larger cell voids the attempt */)
@@ -3170,9 +3260,20 @@ int sv_compress_fused(Solver &sv, bool *fits, int64_t *range, bool cells8 = fals
         k_compress_tr8<R><<<dim3((n + 63) / 64, (n + R - 1) / R), 256, shm, c.stream>>>(n, npad, sv.d_cost, (uint8_t *)sv.cc.p, 0, esc_raw, \
                                                                                        colmin, colmax, ctl);                              \
     } while (0)
-            if (tr8_rows == 256) TD_TR8(256);
+            static const int tr8_wide = getenv("TD_TR8_WIDE") ? atoi(getenv("TD_TR8_WIDE")) : 128;   // > 0: 256-column tiles of this many rows (128 / 256; g3 N = 16 384 step: 64-column tiles 0.838, 256 x 128 0.821, 256 x 256 0.841 ms — the tile shape is not what holds this pass at 3.8 TB/s of traffic)
+#define TD_TR8W(R)                                                                                                                           \
+    do {                                                                                                                                     \
+        const size_t shm = (size_t)256 * (R + 4);                                                                                            \
+        (void)hipFuncSetAttribute((const void *)k_compress_tr8w<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                   \
+        k_compress_tr8w<R><<<dim3((n + 255) / 256, (n + R - 1) / R), 256, shm, c.stream>>>(n, npad, sv.d_cost, (uint8_t *)sv.cc.p, 0, esc_raw, \
+                                                                                          colmin, colmax, ctl);                             \
+    } while (0)
+            if (tr8_wide == 128) TD_TR8W(128);
+            else if (tr8_wide == 256) TD_TR8W(256);
+            else if (tr8_rows == 256) TD_TR8(256);
             else if (tr8_rows == 512) TD_TR8(512);
             else TD_TR8(1024);
+#undef TD_TR8W
 #undef TD_TR8
         } else if (n > 4096)   // tall workgroups: fewer atomics per column; small models need the workgroups instead
             k_compress_tr<8><<<dim3((n + 63) / 64, (n + 511) / 512), 256, 0, c.stream>>>(n, npad, sv.d_cost, (uint32_t *)sv.cc.p, 0, colmin, colmax, ctl);

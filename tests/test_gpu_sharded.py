@@ -301,6 +301,56 @@ def test_bench_sharded_leg_through_rccl(td):
     assert sh["optimal"] and sh["total_cost"] == 10 * 8192 and sh["speedup_vs_single_gpu"] > 0
 
 
+def _blocks_rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["TD_SHARD_FORCE_AR"] = "1"          # issue the collectives with one rank too
+    try:
+        import torch
+        import torch.distributed as dist
+        import taxidispatcher_amd as td
+        from taxidispatcher_amd import _ffi, sharded
+        td.init(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        n = 12288
+        rows = torch.empty((n, n), dtype=torch.int32, device="cuda")
+        _ffi.check(_ffi.lib().td_gen_uniform(n, 3, 10, 40, 0, n, rows.data_ptr()))
+        sh = sharded.HipShard(n, 0, n, rows)
+        try:
+            outs = [sharded.solve_sharded(sh, dist, want_dual=True) for _ in range(2)]   # twice: the workspace and the stream are reused
+            path, left = sharded.solve_sharded.last_path, sharded.solve_sharded.last_left
+        finally:
+            sh.close()
+        ref, ref_total = td.assign(rows)
+        sharded.HipShard.destroy_comm()
+        dist.destroy_process_group()
+        q.put(("ok", (path, left, [int(o[1]) for o in outs], [int(o[2]) for o in outs], bool(np.array_equal(outs[0][0], outs[1][0])),
+                      bool(np.array_equal(outs[0][0], ref)), int(ref_total))))
+    except Exception as e:   # noqa: BLE001
+        q.put(("error", repr(e)))
+
+
+@pytest.mark.gpu
+def test_block_local_start_through_rccl_one_rank(td):
+    """solve_sharded's block-local sequence on an RCCL process group (one rank, TD_SHARD_FORCE_AR=1: the all-gather of the
+    state segments and the scalar all-reduce are issued by RCCL on the stream the library shares with torch): optimal,
+    repeatable, and td_assign's row_to_col when phase A leaves nothing"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_blocks_rccl_worker, args=(_free_port(), q))
+    p.start()
+    status, out = q.get(timeout=300)
+    p.join(timeout=60)
+    assert status == "ok", out
+    path, left, totals, duals, same, same_ref, ref_total = out
+    assert path == "blocks"
+    assert totals == duals == [10 * 12288] * 2 and ref_total == 10 * 12288
+    assert same
+    if left == 0:
+        assert same_ref
+
+
 @pytest.mark.gpu
 def test_bench_two_gpus_end_to_end(td):
     """the first box that shows more than one GPU runs `bench.py --gpus 2` end to end — two ranks, RCCL with
