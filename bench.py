@@ -114,7 +114,7 @@ class Workload:
             self.dem_from = torch.from_numpy(rng.integers(0, S, n).astype(np.int32)).cuda()
             self.expected = None
             self.args = (-1, 250000)
-        elif kind == "g3":
+        elif kind in ("g3", "g3f"):   # g3f: the same model through td_build_assign (no int32 matrix on the device)
             S = 50
             nd = max(1, int(0.363 * n))
             self.cab_to = torch.from_numpy(rng.integers(0, S, n).astype(np.int32)).cuda()
@@ -134,7 +134,7 @@ class Workload:
     def build(self):
         if self.kind == "g1":
             self.ffi.check(self.lib.td_gen_uniform(self.n, self.seed, 10, 40, 0, self.n, self.cost.data_ptr()))
-        elif self.kind in ("wide", "geo2"):
+        elif self.kind in ("wide", "geo2", "g3f"):
             pass   # resident matrix: the step is the solve alone
         else:
             thr, fill = self.args
@@ -143,6 +143,12 @@ class Workload:
                                                   None, 0, fill, thr, 0, self.cost.data_ptr()))
 
     def solve(self):
+        if self.kind == "g3f":
+            thr, fill = self.args
+            self.ffi.check(self.lib.td_build_assign(self.cab_to.data_ptr(), int(self.cab_to.numel()), self.dem_from.data_ptr(),
+                                                    int(self.dem_from.numel()), None, 0, fill, thr, self.r2c.data_ptr(),
+                                                    ctypes.byref(self.total), None))
+            return self.total.value
         self.ffi.check(self.lib.td_assign(self.n, self.cost.data_ptr(), self.r2c.data_ptr(),
                                           ctypes.byref(self.total), None))
         return self.total.value
@@ -698,7 +704,8 @@ def main():
         torch.cuda.empty_cache()
         # g2 twice: the default path (its |a-b| matrix is recognised as a line metric: sorted matching + certificate
         # pass, td_line.hip) and the general solver alone on the same instance (td_set_line_metric(0))
-        for name, kind, en, reps in (("tick_1300x900", "tick", 0, 10), ("g3_n16384", "g3", 16384, 5), ("g2_n16384", "g2", 16384, 10),
+        for name, kind, en, reps in (("tick_1300x900", "tick", 0, 10), ("g3_n16384", "g3", 16384, 5),
+                                     ("g3_n16384_td_build_assign_no_int32_matrix", "g3f", 16384, 5), ("g2_n16384", "g2", 16384, 10),
                                      ("g2_two_cabs_short_n16384", "g2u", 16384, 10), ("g2_n16384_general_solver", "g2", 16384, 2),
                                      ("uniform_0_1e6_n16384_solve_only", "wide", 16384, 3), ("manhattan_2d_n16384_solve_only", "geo2", 16384, 2)):
             try:
@@ -714,7 +721,10 @@ def main():
                 extras[name] = {"ms_per_step": e_ms, "assignments_per_s": w2.n / (e_ms * 1e-3), "solver_stats": td.last_stats()}
                 del w2
                 torch.cuda.empty_cache()
-                if not args.no_cpu_baseline and not name.endswith("general_solver"):
+                if kind == "g3f":
+                    extras[name]["bytes_model"] = ("the fused pass writes N^2 bytes of 1-byte cells (0.27 GB) and reads position arrays only; the "
+                                                   "8 N^2-byte figure of the int32 boundary does not apply to this entry")
+                if not args.no_cpu_baseline and not name.endswith("general_solver") and kind != "g3f":
                     # the stand-in C port on a bounded sample of the same family (N <= 2048, ~2 s), same run, one host core
                     extras[name]["cpu_baseline"] = cpu_baseline(kind, en, min(2.0, args.cpu_seconds))
             except Exception as e:

@@ -111,6 +111,18 @@ TD_API int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_t *t
  * returns the previous setting. */
 TD_API int td_set_line_metric(int on);
 
+/* ---- API #1 of the reference in ONE call: cost build + optimal assignment --------------------------------------
+ * What procedure.py:5-29, greedy_opt.py:102-118 and simulate.py:36-53 expose: solve(distances, demand, cabs) builds the cost
+ * matrix (td_cost_build's positional rule: cost[i][j] = dist[cab_to[i]][dem_from[j]] if below `threshold`, else `fill`;
+ * rows / columns beyond n_s / n_d are `fill`; dist == NULL => |a - b|) and solves it.  Same row_to_col, total and
+ * dual bound as td_cost_build + td_assign — but a model padded with dummy requests (n_s - n_d beyond the shape rule's
+ * margin, fill >= 255: every Simulator.java / simulate.py tick) never exists as an int32 matrix: the fused transposing
+ * compress pass makes each cell from the position arrays straight into its 1- / 4-byte working copy, and the total is
+ * summed from the position arrays again (csrc/td_assign.hip: CellSrc).  Other shapes are built into a library buffer
+ * and solved by td_assign.  Arrays may be host or device memory; td_tick's remainder goes through the same path. */
+TD_API int td_build_assign(const int32_t *cab_to, int n_s, const int32_t *dem_from, int n_d, const int32_t *dist, int S, int32_t fill,
+                           int32_t threshold, int32_t *row_to_col, int64_t *total, int64_t *dual_bound);
+
 /* n*n bytes of 0/1 in the reference's order i = n*cab + cust (solver.py:36-39) */
 TD_API int td_expand_x(int n, const int32_t *row_to_col, uint8_t *x);
 

@@ -206,6 +206,7 @@ long long g_np_plimit = NP_PLIMIT;   // TD_NP_PLIMIT  (tests) lower price limit 
 int g_fuse_t = 2;           // TD_FUSE_T        padded models (dummy requests): one fused transpose + compress pass, no void 1-byte attempt (2: as 1-byte cells + escape when they fit, 1: 4-byte cells, 0: off)
 int g_fuse_spec = 1;        // TD_FUSE_SPEC     the fused pass is speculative (flags read with the final result) when the probe saw a plausible fill value
 int g_fused_rounds = 8;      // TD_FUSED_ROUNDS  bidding rounds launched for a padded model taken by the fused pass
+int g_fuse_gen = 1;          // TD_FUSE_GEN      td_build_assign / td_tick: cells of a padded model made from the position arrays inside the fused pass (no int32 matrix)
 int g_tick_rounds = 5;       // TD_TICK_ROUNDS   ... of td_tick's remainder (n < 2048): 5 rounds make progress on the bench tick, every further launch is ~4 us of nothing
 int g_forest = 1;           // TD_FOREST        cooperative incremental shortest-path forest (k_forest) as the finisher of 4-byte rows
 int g_forest_min_n = 2048;  // TD_FOREST_MIN_N  smallest n it is used for
@@ -264,6 +265,7 @@ void read_tunables()
     if (const char *e = getenv("TD_FUSE_T")) g_fuse_t = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("TD_FUSE_SPEC")) g_fuse_spec = atoi(e) != 0;
     if (const char *e = getenv("TD_FUSED_ROUNDS")) g_fused_rounds = std::max(1, std::min(48, atoi(e)));
+    if (const char *e = getenv("TD_FUSE_GEN")) g_fuse_gen = atoi(e) != 0;
     if (const char *e = getenv("TD_TICK_ROUNDS")) g_tick_rounds = std::max(1, std::min(48, atoi(e)));
     if (const char *e = getenv("TD_FOREST")) g_forest = atoi(e) != 0;
     if (const char *e = getenv("TD_FOREST_MIN_N")) g_forest_min_n = std::max(64, atoi(e));
@@ -1139,6 +1141,29 @@ __device__ __forceinline__ void shape_probe(int n, const int32_t *__restrict__ c
     if (s_last && threadIdx.x == 0) shape_decide(n, ctl);
 }
 
+// A model's cell made on the fly from the position arrays — td_cost_build's positional rule (greedy_opt.py:86-99,
+// simulate.py:17-33, Simulator.java:493-520): cost[i][j] = dist[cab_to[i]][dem_from[j]] for a real pair whose distance is
+// below the threshold, else `fill`.  td_build_assign hands this to the fused transposing compress pass and to k_final
+// instead of an int32 matrix: the 4 N^2-byte matrix of a padded / thresholded model is then neither written nor read.
+struct CellSrc {
+    const int32_t *cab_to = nullptr, *dem_from = nullptr, *dist = nullptr;   // device arrays; dist == null: |a - b|
+    int n_s = 0, n_d = 0, S = 0;
+    int32_t fill = 0, thr = -1;
+    __device__ __forceinline__ int cell(int i, int j) const
+    {
+        if (i >= n_s || j >= n_d) return fill;
+        const int a = cab_to[i], b = dem_from[j];
+        int x;
+        if (dist) {
+            if ((uint32_t)a >= (uint32_t)S || (uint32_t)b >= (uint32_t)S) return fill;   // never index outside the table (k_cost_build)
+            x = dist[(int64_t)a * S + b];
+        } else
+            x = a > b ? a - b : b - a;
+        return (thr < 0 || x < thr) ? x : fill;
+    }
+    __device__ __forceinline__ int4 load4(int i, int j0) const { return make_int4(cell(i, j0), cell(i, j0 + 1), cell(i, j0 + 2), cell(i, j0 + 3)); }
+};
+
 // out[j][i] = in[i][j], 64 x 64 tiles through LDS (both sides coalesced)
 __global__ __launch_bounds__(256) void k_transpose(int n, const int32_t *__restrict__ in, int32_t *__restrict__ out)
 {
@@ -1164,9 +1189,9 @@ __global__ __launch_bounds__(256) void k_transpose(int n, const int32_t *__restr
 // rows = dummy requests are deferred, the range decides the price width) are reduced per workgroup in LDS and
 // merged with one atomic per column and workgroup.  A cell below base or a range beyond 32 bits raises CTL_FLAG:
 // the host then takes the general path.
-template <int RT>
+template <int RT, bool GEN = false>
 __global__ __launch_bounds__(256) void k_compress_tr(int n, int npad, const int32_t *__restrict__ in, uint32_t *__restrict__ out, int base,
-                                                     int *__restrict__ colmin, int *__restrict__ colmax, int *__restrict__ ctl)
+                                                     int *__restrict__ colmin, int *__restrict__ colmax, int *__restrict__ ctl, const CellSrc src = CellSrc())
 {
     __shared__ int32_t tile[64][65];
     __shared__ int s_mn[64], s_mx[64];
@@ -1183,7 +1208,7 @@ __global__ __launch_bounds__(256) void k_compress_tr(int n, int npad, const int3
         __syncthreads();
         for (int r = ty; r < 64; r += 4) {
             const int i = by + r, j = bx + tx;
-            tile[r][tx] = (i < n && j < n) ? in[(int64_t)i * n + j] : 0;
+            tile[r][tx] = (i < n && j < n) ? (GEN ? src.cell(i, j) : in[(int64_t)i * n + j]) : 0;
         }
         __syncthreads();
 #pragma unroll
@@ -1324,9 +1349,10 @@ __global__ __launch_bounds__(256) void k_compress_tr8(int n, int npad, const int
 // The same pass with WIDE tiles: 256 of the caller's columns x TR8W_ROWS rows per workgroup.  Wave w takes the column group
 // [64w, 64w + 64): one instruction of the four waves together reads 4 rows x 1 KiB CONTIGUOUS (the narrow tile read 256-byte
 // pieces at a 64 KiB stride: 3.8 TB/s of traffic), every transposed row leaves as TR8W_ROWS contiguous bytes.
-template <int TR8W_ROWS>
+template <int TR8W_ROWS, bool GEN = false>
 __global__ __launch_bounds__(256) void k_compress_tr8w(int n, int npad, const int32_t *__restrict__ in, uint8_t *__restrict__ out, int base,
-                                                       int esc_raw, int *__restrict__ colmin, int *__restrict__ colmax, int *__restrict__ ctl)
+                                                       int esc_raw, int *__restrict__ colmin, int *__restrict__ colmax, int *__restrict__ ctl,
+                                                       const CellSrc src = CellSrc())
 {
     constexpr int LP = TR8W_ROWS + 4;
     static_assert(TR8W_ROWS % 128 == 0 && TR8W_ROWS <= 256, "a transposed row leaves as TR8W_ROWS / 4 dwords: 32 or 64 lanes");
@@ -1349,7 +1375,12 @@ __global__ __launch_bounds__(256) void k_compress_tr8w(int n, int npad, const in
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int r = 4 * (p0 + u) + rs, i = ry0 + r;
-            if (i < n && vec && jc0 + 3 < n)
+            if constexpr (GEN) {
+                int t4[4];
+#pragma unroll
+                for (int x = 0; x < 4; x++) t4[x] = (i < n && jc0 + x < n) ? src.cell(i, jc0 + x) : esc_raw;
+                v[u] = make_int4(t4[0], t4[1], t4[2], t4[3]);
+            } else if (i < n && vec && jc0 + 3 < n)
                 v[u] = *reinterpret_cast<const int4 *>(in + (int64_t)i * n + jc0);
             else {
                 int t4[4];
@@ -2915,9 +2946,11 @@ __global__ __launch_bounds__(1024) void k_pcommit(int n, PT *__restrict__ pk, in
 // =====================================================================================
 // k_final: total from the original costs + permutation check; k_dual: LP bound
 // =====================================================================================
+template <bool GEN = false>
 __global__ __launch_bounds__(256) void k_final(int n, int nrows, int row0, const int32_t *__restrict__ cost,
                                                const int *__restrict__ r2c, const int *__restrict__ owner,
-                                               unsigned long long *__restrict__ out, int *__restrict__ ctl, int cost_is_transposed = 0)
+                                               unsigned long long *__restrict__ out, int *__restrict__ ctl, int cost_is_transposed = 0,
+                                               const CellSrc src = CellSrc())
 {
     if (ctl[CTL_FLAG]) return;
     long long s = 0;
@@ -2927,7 +2960,8 @@ __global__ __launch_bounds__(256) void k_final(int n, int nrows, int row0, const
         if (j < 0 || j >= n || owner[j] != row0 + i)
             bad = 1;
         else   // the fused transposed solve never materialises the transposed int32 matrix: its cell (i, j) is the caller's (j, i)
-            s += cost_is_transposed ? cost[(int64_t)j * n + i] : cost[(int64_t)i * n + j];
+            s += GEN ? (long long)(cost_is_transposed ? src.cell(j, i) : src.cell(i, j))
+                     : (long long)(cost_is_transposed ? cost[(int64_t)j * n + i] : cost[(int64_t)i * n + j]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -3063,6 +3097,10 @@ struct td_shard {
     bool fused8 = false;       // ... as 1-byte cells with the escape code (u8e, bpc code 6)
     const long long *skip = nullptr;  // device flag of a pending line-metric probe: non-zero makes the compress pass a no-op
     // block-local start (td_blocks.h)
+    bool gen = false;          // td_build_assign: the model's cells are made from the position arrays (gsrc), no int32 matrix exists (yet)
+    CellSrc gsrc;
+    Buf genbuf;                // ... the matrix, should the solve have to leave the fused path
+    Buf gpos;                  // td_build_assign's position arrays / distance table on the device
     bool tick_sized = false;   // td_tick's remainder (hinted, n < 2048): the rounds leave a dozen rows, the serial workgroup is through before a speculative batch + its commit are — no read-back of the free-row count to decide that
     int zs_V = 0;              // diagonal blocks of the whole matrix the 1-byte attempt may start in (0: off)
     bool zs_done = false;      // the compress pass wrote the zero-slice bids of phase A's round 0: sv_phase_a is due
@@ -3071,7 +3109,7 @@ struct td_shard {
     Buf core, core_n, core_t, core_need;   // sparse core of the warm start (td_core_warm.h): lists, their lengths, the smallest value outside, the rows that need their dense row
     void free_all()
     {
-        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &rconst, &misc, &psrec, &tbuf, &xbuf, &fbuf, &cmask, &ob, &esc, &hop, &hoptab, &core, &core_n, &core_t, &core_need};
+        Buf *bs[] = {&stage, &cc, &price, &owner, &r2c, &r2c_full, &bid, &pred, &list, &rowmin, &rconst, &misc, &psrec, &tbuf, &xbuf, &fbuf, &cmask, &ob, &esc, &hop, &hoptab, &core, &core_n, &core_t, &core_need, &genbuf, &gpos};
         for (Buf *b : bs) {
             if (b->p) (void)hipFree(b->p);
             b->p = nullptr;
@@ -3268,14 +3306,23 @@ int sv_compress_fused(Solver &sv, bool *fits, int64_t *range, bool cells8 = fals
         k_compress_tr8w<R><<<dim3((n + 255) / 256, (n + R - 1) / R), 256, shm, c.stream>>>(n, npad, sv.d_cost, (uint8_t *)sv.cc.p, 0, esc_raw, \
                                                                                           colmin, colmax, ctl);                             \
     } while (0)
-            if (tr8_wide == 128) TD_TR8W(128);
+            if (sv.gen) {   // cells made from the position arrays (td_build_assign)
+                const size_t shm = (size_t)256 * (128 + 4);
+                (void)hipFuncSetAttribute((const void *)k_compress_tr8w<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                k_compress_tr8w<128, true><<<dim3((n + 255) / 256, (n + 127) / 128), 256, shm, c.stream>>>(n, npad, nullptr, (uint8_t *)sv.cc.p, 0, esc_raw,
+                                                                                                          colmin, colmax, ctl, sv.gsrc);
+            } else if (tr8_wide == 128) TD_TR8W(128);
             else if (tr8_wide == 256) TD_TR8W(256);
             else if (tr8_rows == 256) TD_TR8(256);
             else if (tr8_rows == 512) TD_TR8(512);
             else TD_TR8(1024);
 #undef TD_TR8W
 #undef TD_TR8
-        } else if (n > 4096)   // tall workgroups: fewer atomics per column; small models need the workgroups instead
+        } else if (sv.gen && n > 4096)
+            k_compress_tr<8, true><<<dim3((n + 63) / 64, (n + 511) / 512), 256, 0, c.stream>>>(n, npad, nullptr, (uint32_t *)sv.cc.p, 0, colmin, colmax, ctl, sv.gsrc);
+        else if (sv.gen)
+            k_compress_tr<1, true><<<dim3((n + 63) / 64, (n + 63) / 64), 256, 0, c.stream>>>(n, npad, nullptr, (uint32_t *)sv.cc.p, 0, colmin, colmax, ctl, sv.gsrc);
+        else if (n > 4096)   // tall workgroups: fewer atomics per column; small models need the workgroups instead
             k_compress_tr<8><<<dim3((n + 63) / 64, (n + 511) / 512), 256, 0, c.stream>>>(n, npad, sv.d_cost, (uint32_t *)sv.cc.p, 0, colmin, colmax, ctl);
         else
             k_compress_tr<1><<<dim3((n + 63) / 64, (n + 63) / 64), 256, 0, c.stream>>>(n, npad, sv.d_cost, (uint32_t *)sv.cc.p, 0, colmin, colmax, ctl);
@@ -3732,9 +3779,12 @@ int sv_totals_t(Solver &sv, bool want_dual)
     using PT = typename Tr<CT>::PT;
     unsigned long long *out = (unsigned long long *)((char *)sv.misc.p + 1024);
     ProfScope ps(TD_K_FINAL);
-    if (sv.nrows > 0)
-        k_final<<<std::min((sv.nrows + 255) / 256, 256), 256, 0, c.stream>>>(sv.n, sv.nrows, sv.row0, sv.d_cost, (const int *)sv.r2c.p,
-                                                                            (const int *)sv.owner.p, out, (int *)sv.misc.p, sv.fused_t ? 1 : 0);
+    if (sv.nrows > 0 && sv.gen)
+        k_final<true><<<std::min((sv.nrows + 255) / 256, 256), 256, 0, c.stream>>>(sv.n, sv.nrows, sv.row0, nullptr, (const int *)sv.r2c.p,
+                                                                                  (const int *)sv.owner.p, out, (int *)sv.misc.p, sv.fused_t ? 1 : 0, sv.gsrc);
+    else if (sv.nrows > 0)
+        k_final<false><<<std::min((sv.nrows + 255) / 256, 256), 256, 0, c.stream>>>(sv.n, sv.nrows, sv.row0, sv.d_cost, (const int *)sv.r2c.p,
+                                                                                   (const int *)sv.owner.p, out, (int *)sv.misc.p, sv.fused_t ? 1 : 0);
     if (want_dual && (sv.nrows > 0 || sv.row0 == 0))
         k_dual<CT><<<std::max(1, std::min((sv.nrows + 3) / 4, c.n_cu * 8)), 256, 0, c.stream>>>(
             sv.n, sv.nrows, sv.row0, sv.nchunks, (const CT *)sv.cc.p, (const PT *)sv.price.p, (const int32_t *)sv.rowmin.p, out);
@@ -3956,14 +4006,59 @@ namespace {
 struct AssignHint {
     bool valid = false;
     int const_cols = 0, const_rows = 0, fill = 0;
+    bool tick = false;   // td_tick's remainder: its own round count, no speculative batches (tick-sized tuning)
+    bool gen = false;    // the cells come from position arrays (src), `cost` is a placeholder
+    CellSrc src;
 } g_hint;
 }  // namespace
 void td::assign_hint_padded(int const_cols, int const_rows, int32_t fill)
 {
+    g_hint = AssignHint();
     g_hint.valid = true;
     g_hint.const_cols = const_cols;
     g_hint.const_rows = const_rows;
     g_hint.fill = fill;
+    g_hint.tick = true;
+}
+
+// Cost build + optimal assignment from DEVICE position arrays without the int32 matrix where the model allows it: a model
+// padded with dummy requests (n_s - n_d beyond the shape rule's margin: every Simulator.java / simulate.py tick) goes
+// through the fused transposing compress pass with its cells made on the fly (CellSrc), k_final sums them the same way;
+// any other shape is built into a library buffer and handed to td_assign as it is.
+int td::build_assign_device(const int32_t *d_cab, int n_s, const int32_t *d_dem, int n_d, const int32_t *d_dist, int S, int32_t fill,
+                            int32_t threshold, bool tick, int32_t *row_to_col, int64_t *total, int64_t *dual_bound)
+{
+    read_tunables();
+    const int n = std::max(n_s, n_d);
+    Solver &sv = g_default;
+    int rc;
+    if ((rc = ensure(sv.misc, 4096))) return rc;
+    const int const_cols = n - n_d, const_rows = n - n_s;
+    const int margin = n / 256 > 32 ? n / 256 : 32;
+    const bool fuse = g_fuse_gen && g_fuse_t && g_shape && !g_solver_eps && n >= 64 && const_cols >= 16 && const_cols - const_rows >= margin &&
+                      fill >= 255 && (int64_t)fill <= NP_RANGE;
+    if (!fuse) {
+        if ((rc = ensure(sv.genbuf, sizeof(int32_t) * (size_t)n * n))) return rc;
+        if ((rc = td::cost_build_async(d_cab, n_s, d_dem, n_d, d_dist, S, fill, threshold, (int32_t *)sv.genbuf.p))) return rc;
+        if (tick) td::assign_hint_padded(const_cols, const_rows, fill);
+        return td_assign(n, (const int32_t *)sv.genbuf.p, row_to_col, total, dual_bound);
+    }
+    g_hint = AssignHint();
+    g_hint.valid = true;
+    g_hint.const_cols = const_cols;
+    g_hint.const_rows = const_rows;
+    g_hint.fill = fill;
+    g_hint.tick = tick;
+    g_hint.gen = true;
+    g_hint.src.cab_to = d_cab;
+    g_hint.src.dem_from = d_dem;
+    g_hint.src.dist = d_dist;
+    g_hint.src.n_s = n_s;
+    g_hint.src.n_d = n_d;
+    g_hint.src.S = S;
+    g_hint.src.fill = fill;
+    g_hint.src.thr = threshold;
+    return td_assign(n, (const int32_t *)sv.misc.p /* placeholder: no matrix exists */, row_to_col, total, dual_bound);
 }
 
 // =====================================================================================
@@ -4017,6 +4112,22 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     const int hint_margin = n / 256 > 32 ? n / 256 : 32;
     const bool hinted_fuse = hint.valid && g_fuse_t && g_shape && !g_solver_eps && n >= 64 && hint.const_cols >= 16 &&
                              hint.const_cols - hint.const_rows >= hint_margin && hint.fill >= 255 && (int64_t)hint.fill <= NP_RANGE;
+    sv.gen = hint.valid && hint.gen;
+    sv.gsrc = hint.src;
+    // the cells of a td_build_assign call exist only as position arrays; the moment the solve leaves the fused path they are
+    // written out as the int32 matrix every other pass reads
+    auto materialise = [&]() -> int {
+        if (!sv.gen) return TD_OK;
+        int mrc;
+        if ((mrc = ensure(sv.genbuf, sizeof(int32_t) * (size_t)n * n))) return mrc;
+        if ((mrc = td::cost_build_async(sv.gsrc.cab_to, sv.gsrc.n_s, sv.gsrc.dem_from, sv.gsrc.n_d, sv.gsrc.dist, sv.gsrc.S, sv.gsrc.fill, sv.gsrc.thr,
+                                        (int32_t *)sv.genbuf.p)))
+            return mrc;
+        sv.d_cost = (const int32_t *)sv.genbuf.p;
+        sv.gen = false;
+        return TD_OK;
+    };
+    if (sv.gen && !hinted_fuse && (rc = materialise())) return rc;
     if (!hinted_fuse && g_line && n >= g_line_min_n && !g_solver_eps) {
         if ((rc = line_probe_launch(n, sv.d_cost, &sv.skip))) return rc;
         line_pending = true;
@@ -4041,8 +4152,8 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
         sv.fused_t = true;
         transposed = true;
         hinted_range = hint.fill;
-        max_rounds = std::min(max_rounds, n < 2048 ? std::min(g_fused_rounds, g_tick_rounds) : g_fused_rounds);
-        sv.tick_sized = n < 2048;
+        max_rounds = std::min(max_rounds, (hint.tick && n < 2048) ? std::min(g_fused_rounds, g_tick_rounds) : g_fused_rounds);
+        sv.tick_sized = hint.tick && n < 2048;
     }
 restart:
     for (int orient = 0; orient < 2 && !solved; orient++) {
@@ -4331,6 +4442,7 @@ restart:
             fused_spec = false;
             max_rounds = g_max_rounds;
             early_check = true;
+            if ((rc = materialise())) return rc;   // (td_build_assign: the general path reads the matrix)
             goto restart;
         }
         if (bpc == 5 && flag) {   // a price reached the 32-bit limit: the attempt is void, redo with 64-bit prices
@@ -4388,6 +4500,42 @@ restart:
     if (total) *total = tot;
     if (dual_bound) *dual_bound = dual;
     return TD_OK;
+}
+
+extern "C" int td_build_assign(const int32_t *cab_to, int n_s, const int32_t *dem_from, int n_d, const int32_t *dist, int S, int32_t fill,
+                               int32_t threshold, int32_t *row_to_col, int64_t *total, int64_t *dual_bound)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (n_s < 0 || n_d < 0) return fail(TD_EINVAL, "negative sizes n_s=%d n_d=%d", n_s, n_d);
+    const int n = std::max(n_s, n_d);
+    if (n == 0) {   // simulate.py:38  n == 0 -> (0, [], 0)
+        if (total) *total = 0;
+        if (dual_bound) *dual_bound = 0;
+        return TD_OK;
+    }
+    if ((n_s && !cab_to) || (n_d && !dem_from) || !row_to_col) return fail(TD_EINVAL, "null array");
+    if (dist && S <= 0) return fail(TD_EINVAL, "dist given but S=%d", S);
+    // the (small) position arrays and a host distance table: once on the device, in a buffer of the solver's workspace
+    Solver &sv = g_default;
+    int rc;
+    const size_t words = (size_t)n_s + n_d + ((dist && !is_device_ptr(dist)) ? (size_t)S * S : 0) + 16;
+    if ((rc = ensure(sv.gpos, sizeof(int32_t) * words))) return rc;
+    int32_t *buf = (int32_t *)sv.gpos.p;
+    const int32_t *d_cab = cab_to, *d_dem = dem_from, *d_dist = dist;
+    if (n_s && !is_device_ptr(cab_to)) {
+        TD_HIP(hipMemcpyAsync(buf, cab_to, sizeof(int32_t) * (size_t)n_s, hipMemcpyHostToDevice, c.stream));
+        d_cab = buf;
+    }
+    if (n_d && !is_device_ptr(dem_from)) {
+        TD_HIP(hipMemcpyAsync(buf + n_s, dem_from, sizeof(int32_t) * (size_t)n_d, hipMemcpyHostToDevice, c.stream));
+        d_dem = buf + n_s;
+    }
+    if (dist && !is_device_ptr(dist)) {
+        TD_HIP(hipMemcpyAsync(buf + n_s + n_d, dist, sizeof(int32_t) * (size_t)S * S, hipMemcpyHostToDevice, c.stream));
+        d_dist = buf + n_s + n_d;
+    }
+    return td::build_assign_device(d_cab, n_s, d_dem, n_d, d_dist, S, fill, threshold, false, row_to_col, total, dual_bound);
 }
 
 extern "C" int td_set_line_metric(int on)

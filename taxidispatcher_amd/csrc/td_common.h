@@ -69,6 +69,10 @@ void line_release_workspace();
 // td_assign.hip: a hint for the NEXT td_assign call of this process (consumed by it): the matrix is a model padded with
 // `const_cols` dummy requests and `const_rows` dummy cabs of value `fill` (td_tick knows this from its position arrays)
 void assign_hint_padded(int const_cols, int const_rows, int32_t fill);
+// td_assign.hip: cost build + optimal assignment from DEVICE position arrays (td_build_assign after staging, td_tick's remainder);
+// a model padded with dummy requests never exists as an int32 matrix (its cells are made inside the fused compress pass)
+int build_assign_device(const int32_t *d_cab, int n_s, const int32_t *d_dem, int n_d, const int32_t *d_dist, int S, int32_t fill,
+                        int32_t threshold, bool tick, int32_t *row_to_col, int64_t *total, int64_t *dual_bound);
 // td_lcm.hip: td_lcm with the candidate cells' value range given by the caller (no min / max pass, no host round trip);
 // a wrong hint is detected on the device and the call is redone with the measured range
 int lcm_hinted(int n, const int32_t *cost, int32_t mask, int32_t threshold, int stop_value_on, int32_t stop_value, int stop_size,

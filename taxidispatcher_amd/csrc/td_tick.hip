@@ -197,11 +197,9 @@ extern "C" int td_tick(const int32_t *cab_to, int n_s, const int32_t *dem_from, 
     // *total (0) are not touched; the caller sees it as lcm_last_min == fill with the LCM having run.
     const bool lcm_ran = stop_size >= 0 && stop_size < n;
     if (n2 > 0 && !(lcm_ran && last_min == fill)) {
-        if ((rc = ensure(t.cost_b, sizeof(int32_t) * (size_t)n2 * n2))) return rc;
-        int32_t *d_b = (int32_t *)t.cost_b.p;
-        if ((rc = td::cost_build_async(d_cab2, kc, d_dem2, kd, d_dist, S, fill, threshold, d_b))) return rc;
-        td::assign_hint_padded(n2 - kd, n2 - kc, fill);   // dummy requests / dummy cabs of the remainder: no probe, no 1-byte attempt
-        if ((rc = td_assign(n2, d_b, row_to_col, total, nullptr))) return rc;   // ends with a stream synchronisation
+        // the remainder's cost build + optimal assignment: its cells are made from the kept position arrays inside the fused
+        // compress pass when the model is padded with dummy requests (every reference tick), the matrix is never written
+        if ((rc = td::build_assign_device(d_cab2, kc, d_dem2, kd, d_dist, S, fill, threshold, true, row_to_col, total, nullptr))) return rc;   // ends with a stream synchronisation
     } else {
         TD_HIP(hipStreamSynchronize(c.stream));
     }

@@ -10,6 +10,7 @@ Reference map (file:line in boguszjelinski/taxidispatcher):
     calculate_cost_by_id  procedure.py:6-12
     solve                 greedy_opt.py:102-118 / simulate.py:36-53  -> (n, x, cost)
     procedure_solve       procedure.py:5-29                           -> x
+    build_assign          the same API #1 without handing the matrix back (td_build_assign)
     solve_cost            solver.py:11-27                             -> x
     LCM                   greedy_opt.py:61-82 / simulate.py:76-98
     LCM_heuristic         heuristic.py:24-33
@@ -116,6 +117,27 @@ def set_line_metric(on):
     return bool(_ffi.lib().td_set_line_metric(1 if on else 0))
 
 
+def build_assign(cab_to, dem_from, distances=None, fill=BIG_COST, threshold=-1, want_dual=False):
+    """td_build_assign: cost build + optimal assignment in one call (the reference's solve(distances, demand, cabs),
+    procedure.py:5-29 / greedy_opt.py:102-118 / simulate.py:36-53, without handing the matrix back).  A model padded
+    with dummy requests never exists as an int32 matrix on the device.  Returns (n, row_to_col int32[n], total[, dual])."""
+    lib = _ffi.lib()
+    cab = cab_to if hasattr(cab_to, "data_ptr") else _ffi.as_i32(cab_to)
+    dem = dem_from if hasattr(dem_from, "data_ptr") else _ffi.as_i32(dem_from)
+    n_s, n_d = int(cab.shape[0]), int(dem.shape[0])
+    n = max(n_s, n_d)
+    dptr, S, keep = _dist_arg(distances)
+    r2c = np.empty(n, np.int32)
+    total, dual = ctypes.c_int64(0), ctypes.c_int64(0)
+    _ffi.check(lib.td_build_assign(_ffi.addr(cab) if n_s else None, n_s, _ffi.addr(dem) if n_d else None, n_d, dptr, S, int(fill),
+                                   int(threshold), _ffi.addr(r2c) if n else None, ctypes.byref(total),
+                                   ctypes.byref(dual) if want_dual else None))
+    del keep
+    if want_dual:
+        return n, r2c, int(total.value), int(dual.value)
+    return n, r2c, int(total.value)
+
+
 def expand_x(n, row_to_col):
     """row_to_col -> the reference's n*n 0/1 vector, index n*cab + cust (solver.py:36-39)."""
     x = np.zeros(n * n, np.uint8)
@@ -165,10 +187,24 @@ def solve_cost(n, cost):
 
 def procedure_solve(distances, demand, cabs):
     """procedure.py:5-29 solve(distances, demand, cabs) -> x (length n*n, x[n*cab+cust] == 1)."""
-    n, cost = calculate_cost_by_id(distances, demand, cabs)
+    c_id, _, c_to = _records(cabs)
+    d_id, d_frm, _ = _records(demand)
+    n = max(c_to.size, d_frm.size)
     if n == 0:
         return np.zeros(0, np.uint8)
-    r2c, _ = assign(cost, n)
+    ids_ok = (distances is not None and c_id.size and d_id.size and c_id.min() >= 0 and d_id.min() >= 0 and c_id.max() < n and d_id.max() < n
+              and np.unique(c_id).size == c_id.size and np.unique(d_id).size == d_id.size)
+    if not ids_ok:   # (ids outside 0..n-1 or repeated: the scatter of procedure.py:12 decides, build the matrix the same way)
+        n, cost = calculate_cost_by_id(distances, demand, cabs)
+        r2c, _ = assign(cost, n)
+        return expand_x(n, r2c)
+    # procedure.py:9-12 addresses the cells by the records' ids: the same matrix as the positional rule over arrays ORDERED BY ID
+    # (a missing id is a stand outside the table: td_cost_build never indexes outside it, the cell stays at the fill value)
+    to_by_id = np.full(n, -1, np.int32)
+    frm_by_id = np.full(n, -1, np.int32)
+    to_by_id[c_id] = c_to
+    frm_by_id[d_id] = d_frm
+    _, r2c, _ = build_assign(to_by_id, frm_by_id, distances, fill=n * n, threshold=-1)
     return expand_x(n, r2c)
 
 
