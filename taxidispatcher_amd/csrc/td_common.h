@@ -81,6 +81,10 @@ int lcm_hinted(int n, const int32_t *cost, int32_t mask, int32_t threshold, int 
 // td_core.hip: td_cost_build for device-resident library buffers, without the trailing stream synchronisation (td_tick)
 int cost_build_async(const int32_t *cab_to, int n_s, const int32_t *dem_from, int n_d, const int32_t *dist, int S, int32_t fill,
                      int32_t threshold, int32_t *cost);
+// td_lcm.hip: td_tick's LCM of a thresholded |a - b| model on <= 64 stands straight from the position arrays (no matrix);
+// *ok = 0: not such a model, nothing done
+int lcm_stands(int n_s, int n_d, const int32_t *d_cab_to, const int32_t *d_dem_from, int32_t fill, int32_t threshold, int stop_size,
+               int32_t *rows, int32_t *cols, int32_t *n_pairs, int32_t *last_min, int *ok);
 void prof_begin(int k);
 void prof_end(int k);
 void prof_flush();

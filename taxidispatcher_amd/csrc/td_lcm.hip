@@ -1367,3 +1367,237 @@ extern "C" int td_pool2(int n, const int32_t *from, const int32_t *to, const int
     if (n_pairs) *n_pairs = k;
     return TD_OK;
 }
+
+// =====================================================================================
+// td_tick's LCM on STANDS (round 4).  The Simulator's model is cost = |cab stand - request stand| below DROP_TIME
+// on N_STANDS = 50 stands (Simulator.java:110,493-520,553-560): every cab of a stand has the SAME row, every request
+// of a stand the same column.  The lowest-cost method (Simulator.java:523-549: repeat { first minimum in row-major order;
+// mask its row and column }) then never needs the matrix:
+//   * at value L a cab at stand a can only take a request at stand a - L or a + L, and among those the one with the
+//     smallest index — the HEAD of that stand's queue of untaken requests (requests of a stand are taken in index order);
+//   * among the cabs of a stand the one with the smallest index goes first (same reason): per stand two counters
+//     describe everything that has happened;
+//   * value 0: the stands are independent — stand a pairs its t-th cab with its t-th request, t < min(cabs, requests);
+//     the picks of a level come out in increasing row order, so a pick's place in the list is the rank of its row among
+//     the picked rows (a bitmap + prefix popcounts), and the `limit` smallest rows are the ones the loop gets to;
+//   * value L >= 1: one pick at a time — every stand (a lane) offers its smallest untaken cab if one of its two queues
+//     has a head, the wave minimum is the next row, its column the smaller of the two heads.
+// One workgroup; the typical tick (supply above demand at most stands) is done at value 0: ~10 us instead of the ~110 us
+// of the level-list build + greedy walk over the 1300 x 900 matrix, whose 6.8 MB are then never written either.
+// Positions outside 0..63 (or a threshold above 64) raise a flag: the caller takes the general path.
+// =====================================================================================
+namespace {
+
+constexpr int LST_MAXN = 2048;   // cabs / requests the one-workgroup kernel holds in LDS (4 arrays of them: 32 KB)
+
+__device__ __forceinline__ int lst_wave_min(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_lcm_stands(int n_s, int n_d, int thr, int limit, int32_t fill, const int32_t *__restrict__ cab_to,
+                                                    const int32_t *__restrict__ dem_from, int32_t *__restrict__ rows,
+                                                    int32_t *__restrict__ cols, LcmOut *__restrict__ out, int *__restrict__ bad)
+{
+    __shared__ int s_pos_c[LST_MAXN], s_pos_r[LST_MAXN];     // stand of every cab / request
+    __shared__ int s_clist[LST_MAXN], s_rlist[LST_MAXN];     // cabs / requests grouped by stand, index order inside a stand
+    __shared__ int s_cnt_c[64], s_cnt_r[64], s_off_c[64], s_off_r[64];
+    __shared__ unsigned short s_sl[2][64][64];               // per side: elements of stand a in slice t (then their offset)
+    __shared__ uint32_t s_bits[LST_MAXN / 32];
+    __shared__ int s_wpre[LST_MAXN / 32 + 1];
+    __shared__ int s_bad, s_k, s_done;
+    __shared__ long long s_total;
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < 64) s_cnt_c[tid] = 0, s_cnt_r[tid] = 0;
+    if (tid == 0) s_bad = 0, s_k = 0, s_done = 0, s_total = 0, s_last = fill;
+    for (int i = tid; i < LST_MAXN / 32; i += 256) s_bits[i] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n_s; i += 256) {
+        const int a = cab_to[i];
+        s_pos_c[i] = a;
+        if ((unsigned)a >= 64u) s_bad = 1;
+        else atomicAdd(&s_cnt_c[a], 1);
+    }
+    for (int i = tid; i < n_d; i += 256) {
+        const int b = dem_from[i];
+        s_pos_r[i] = b;
+        if ((unsigned)b >= 64u) s_bad = 1;
+        else atomicAdd(&s_cnt_r[b], 1);
+    }
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0) *bad = 1;
+        return;
+    }
+    if (tid == 0) {
+        int oc = 0, orr = 0;
+        for (int a = 0; a < 64; a++) {
+            s_off_c[a] = oc;
+            s_off_r[a] = orr;
+            oc += s_cnt_c[a];
+            orr += s_cnt_r[a];
+        }
+    }
+    // stable grouping by stand (index order inside a stand) without a 1300-step walk per stand: thread t of wave 0 (cabs) /
+    // wave 1 (requests) owns a contiguous slice of the elements, counts its slice per stand into s_sl[side][t][stand],
+    // lane `stand` turns the 64 slice counts of its stand into offsets, then every thread places its slice
+    if (w < 2) {
+        const int cnt = w == 0 ? n_s : n_d;
+        const int *pos = w == 0 ? s_pos_c : s_pos_r;
+        const int per = (cnt + 63) / 64, lo = lane * per, hi = min(cnt, lo + per);
+        unsigned short *mine = &s_sl[w][lane][0];
+        for (int a = 0; a < 64; a++) mine[a] = 0;
+        for (int i = lo; i < hi; i++) mine[pos[i]]++;
+    }
+    __syncthreads();
+    if (w < 2) {   // lane = stand: exclusive prefix over the 64 slices
+        int acc = 0;
+        for (int t = 0; t < 64; t++) {
+            const int v = s_sl[w][t][lane];
+            s_sl[w][t][lane] = (unsigned short)acc;
+            acc += v;
+        }
+    }
+    __syncthreads();
+    if (w < 2) {
+        const int cnt = w == 0 ? n_s : n_d;
+        const int *pos = w == 0 ? s_pos_c : s_pos_r;
+        const int *off = w == 0 ? s_off_c : s_off_r;
+        int *list = w == 0 ? s_clist : s_rlist;
+        const int per = (cnt + 63) / 64, lo = lane * per, hi = min(cnt, lo + per);
+        unsigned short *mine = &s_sl[w][lane][0];
+        for (int i = lo; i < hi; i++) {
+            const int a = pos[i];
+            list[off[a] + mine[a]] = i;
+            mine[a]++;
+        }
+    }
+    __syncthreads();
+    // ---- value 0: every stand pairs its t-th cab with its t-th request; the picked rows are marked in a bitmap
+    const int m0 = (tid < 64) ? min(s_cnt_c[tid], s_cnt_r[tid]) : 0;
+    if (tid < 64 && thr > 0)
+        for (int t = 0; t < m0; t++) {
+            const int r = s_clist[s_off_c[tid] + t];
+            atomicOr(&s_bits[r >> 5], 1u << (r & 31));
+        }
+    __syncthreads();
+    const int nw32 = (n_s + 31) / 32;
+    if (tid == 0) {   // prefix of the word popcounts (<= 128 words)
+        int acc = 0;
+        for (int i = 0; i < nw32; i++) {
+            s_wpre[i] = acc;
+            acc += __popc(s_bits[i]);
+        }
+        s_wpre[nw32] = acc;
+    }
+    __syncthreads();
+    const int p0 = thr > 0 ? s_wpre[nw32] : 0;   // picks available at value 0
+    const int take0 = min(p0, limit);
+    if (tid < 64 && thr > 0)
+        for (int t = 0; t < m0; t++) {
+            const int r = s_clist[s_off_c[tid] + t];
+            const int rank = s_wpre[r >> 5] + __popc(s_bits[r >> 5] & ((1u << (r & 31)) - 1u));
+            if (rank < take0) {
+                rows[rank] = r;
+                cols[rank] = s_rlist[s_off_r[tid] + t];
+            }
+        }
+    // how far every stand got at value 0 (only picks of rank < take0 happened)
+    __shared__ int s_ca[64], s_rb[64];
+    if (tid < 64) {
+        int used = 0;
+        if (thr > 0) {
+            if (take0 == p0)
+                used = m0;
+            else   // the loop stopped inside value 0: the stand's picks with rank < take0 (its cabs are in increasing order)
+                for (int t = 0; t < m0; t++) {
+                    const int r = s_clist[s_off_c[tid] + t];
+                    const int rank = s_wpre[r >> 5] + __popc(s_bits[r >> 5] & ((1u << (r & 31)) - 1u));
+                    used += rank < take0 ? 1 : 0;
+                }
+        }
+        s_ca[tid] = used;
+        s_rb[tid] = used;
+    }
+    __syncthreads();
+    int k = take0;
+    if (w == 0) {
+        long long total = 0;
+        int last = take0 > 0 ? 0 : fill;
+        bool done = k >= limit;
+        int ca = s_ca[lane], rb = s_rb[lane];
+        const int ncab = s_cnt_c[lane], nreq = s_cnt_r[lane], offc = s_off_c[lane], offr = s_off_r[lane];
+        for (int L = 1; L < thr && !done; L++) {
+            for (;;) {
+                const int h = rb < nreq ? s_rlist[offr + rb] : INT_MAX;     // head of this stand's request queue
+                const int hl = __shfl(h, (lane - L) & 63), hr = __shfl(h, (lane + L) & 63);
+                const int req = min(lane - L >= 0 ? hl : INT_MAX, lane + L < 64 ? hr : INT_MAX);
+                const int cand = (ca < ncab && req != INT_MAX) ? s_clist[offc + ca] : INT_MAX;
+                const int best = lst_wave_min(cand);
+                if (best == INT_MAX) break;   // nothing left at this value
+                const unsigned long long wm = __ballot(cand == best);
+                const int wl = __builtin_ctzll(wm);
+                const int c = __shfl(req, wl);
+                const int bst = s_pos_r[c];   // the stand whose queue loses its head
+                if (lane == 0) {
+                    rows[k] = best;
+                    cols[k] = c;
+                }
+                if (lane == wl) ca++;
+                if (lane == bst) rb++;
+                k++;
+                total += L;
+                last = L;
+                if (k >= limit) {
+                    done = true;
+                    break;
+                }
+            }
+        }
+        if (lane == 0) {
+            out->n_pairs = k;
+            out->last_min = done ? last : fill;   // lists exhausted before the size limit: the next look at the matrix sees big_cost (Simulator.java:538)
+            out->total = total;
+        }
+    }
+}
+
+}  // namespace
+
+// td_tick: the LCM of a thresholded |a - b| model straight from the position arrays (k_lcm_stands).  *ok = 0: the model is
+// not of that kind (a position outside 0..63) — nothing was done, the caller builds the matrix and calls lcm_hinted.
+int td::lcm_stands(int n_s, int n_d, const int32_t *d_cab_to, const int32_t *d_dem_from, int32_t fill, int32_t threshold, int stop_size,
+                   int32_t *rows, int32_t *cols, int32_t *n_pairs, int32_t *last_min, int *ok)
+{
+    Ctx &c = ctx();
+    const int n = std::max(n_s, n_d);
+    *ok = 0;
+    if (threshold < 1 || threshold > 64 || n_s > LST_MAXN || n_d > LST_MAXN || stop_size < 0 || stop_size >= n) return TD_OK;
+    int rc;
+    if ((rc = ensure(c.lcm_b, sizeof(int32_t) * 2 * (size_t)n))) return rc;
+    if ((rc = ensure(c.lcm_d, 512 + sizeof(LcmsInfo) * (size_t)c.n_cu * 4))) return rc;
+    int32_t *d_rows = (int32_t *)c.lcm_b.p, *d_cols = d_rows + n;
+    LcmOut *d_out = (LcmOut *)c.lcm_d.p;
+    int *d_bad = (int *)((char *)c.lcm_d.p + 104);
+    ProfScope ps(TD_K_LCM);
+    TD_HIP(hipMemsetAsync(c.lcm_d.p, 0, 128, c.stream));
+    k_lcm_stands<<<1, 256, 0, c.stream>>>(n_s, n_d, threshold, n - stop_size, fill, d_cab_to, d_dem_from, d_rows, d_cols, d_out, d_bad);
+    TD_HIP(hipGetLastError());
+    TD_HIP(hipMemcpyAsync(c.pinned, c.lcm_d.p, 128, hipMemcpyDeviceToHost, c.stream));
+    TD_HIP(hipStreamSynchronize(c.stream));
+    if (*(const int *)((const char *)c.pinned + 104)) return TD_OK;   // not a model on <= 64 stands
+    const LcmOut *ho = (const LcmOut *)c.pinned;
+    const int k = ho->n_pairs;
+    const int32_t lm = ho->last_min;
+    if (k > 0) {
+        TD_HIP(hipMemcpyAsync(rows, d_rows, sizeof(int32_t) * (size_t)k, hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipMemcpyAsync(cols, d_cols, sizeof(int32_t) * (size_t)k, hipMemcpyDeviceToHost, c.stream));
+    }
+    *n_pairs = k;
+    *last_min = lm;
+    *ok = 1;
+    return TD_OK;
+}

@@ -99,7 +99,6 @@ extern "C" int td_tick(const int32_t *cab_to, int n_s, const int32_t *dem_from, 
         return fail(TD_EINVAL, "td_tick hands its (small) results to HOST arrays");
     TickBufs &t = g_tick;
     int rc;
-    if ((rc = ensure(t.cost_a, sizeof(int32_t) * (size_t)n * n))) return rc;
     if ((rc = ensure(t.pos, sizeof(int32_t) * 4 * (size_t)n + (dist && !is_device_ptr(dist) ? sizeof(int32_t) * (size_t)S * S : 0)))) return rc;
     if ((rc = ensure(t.keep, sizeof(int32_t) * (2 * (size_t)n + 4)))) return rc;
     const size_t pin_need = sizeof(int32_t) * (2 * (size_t)n + 4);
@@ -162,12 +161,22 @@ extern "C" int td_tick(const int32_t *cab_to, int n_s, const int32_t *dem_from, 
         if ((rc = put_small(dist, S * S, dd))) return rc;
         d_dist = dd;
     }
-    int32_t *d_a = (int32_t *)t.cost_a.p;
-    if ((rc = td::cost_build_async(d_cab, n_s, d_dem, n_d, d_dist, S, fill, threshold, d_a))) return rc;
     int k = 0;
     int64_t lcm_total = 0;
     int32_t last_min = fill;
-    if (stop_size >= 0 && stop_size < n) {
+    // the Simulator's own model — |a - b| below DROP_TIME on <= 64 stands — needs no matrix for its LCM (k_lcm_stands)
+    int on_stands = 0;
+    static const bool use_stands = !(getenv("TD_LCM_STANDS") && atoi(getenv("TD_LCM_STANDS")) == 0);
+    if (use_stands && !dist && stop_size >= 0 && stop_size < n) {
+        if ((rc = td::lcm_stands(n_s, n_d, d_cab, d_dem, fill, threshold, stop_size, lcm_rows, lcm_cols, &k, &last_min, &on_stands))) return rc;
+    }
+    int32_t *d_a = nullptr;
+    if (!on_stands && stop_size >= 0 && stop_size < n) {
+        if ((rc = ensure(t.cost_a, sizeof(int32_t) * (size_t)n * n))) return rc;
+        d_a = (int32_t *)t.cost_a.p;
+        if ((rc = td::cost_build_async(d_cab, n_s, d_dem, n_d, d_dist, S, fill, threshold, d_a))) return rc;
+    }
+    if (!on_stands && stop_size >= 0 && stop_size < n) {
         // Simulator.java:523-549: stop on big_cost or when MAX_NON_LCM rows are left; dummies are never summed
         // every real cell of a thresholded model lies in 0 .. threshold - 1 (distances are not negative): the level lists
         // are laid out without a min / max pass; a table with a negative distance is caught on the device and redone

@@ -153,7 +153,7 @@ def test_config5_tick_in_one_call_gpu(td):
             assert t["lcm_min_val"] == lm
         assert t["kept_cabs"].tolist() == keep_c.tolist() and t["kept_dems"].tolist() == keep_d.tolist()
         assert t["n_rest"] == n2
-        if len(rows) and lm == BIG_COST:   # Simulator.java:188-189: the LCM ended on big_cost, nothing goes to the solver
+        if 0 <= stop < max(len(cab_to), len(dem_from)) and lm == BIG_COST:   # Simulator.java:188-189: the LCM ran and ended on big_cost, nothing goes to the solver
             assert not t["solved"] and t["total"] == 0 and len(t["row_to_col"]) == 0
             continue
         assert t["solved"] and t["total"] == tot

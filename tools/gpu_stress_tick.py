@@ -51,7 +51,7 @@ while time.time() < t_end and cnt < max_cnt:
         ok = ok and (not len(rows) or t["lcm_min_val"] == lm)
         ok = ok and t["kept_cabs"].tolist() == keep_c.tolist() and t["kept_dems"].tolist() == keep_d.tolist()
         ok = ok and t["n_rest"] == n2
-        if len(rows) and lm == BIG:   # Simulator.java:188-189: the LCM ended on big_cost, the tick has nothing for the solver
+        if 0 <= stop < max(ns, nd) and lm == BIG:   # Simulator.java:188-189: the LCM ran and ended on big_cost (possibly at its first look), the tick has nothing for the solver
             ok = ok and not t["solved"] and t["total"] == 0 and len(t["row_to_col"]) == 0
             kinds["tick without a solve"] = kinds.get("tick without a solve", 0) + 1
         else:
@@ -60,6 +60,10 @@ while time.time() < t_end and cnt < max_cnt:
             ok = ok and sorted(r2c.tolist()) == list(range(n2))
             ok = ok and (n2 == 0 or int(cost2[np.arange(n2), r2c].astype(np.int64).sum()) == tot)
         desc = (what, ns, nd, S, dist is not None, drop, stop)
+        if not ok and os.environ.get("STRESS_VERBOSE"):
+            print("  detail: lcm rows ok %s cols ok %s (k %d vs %d) lm %s vs %s kept ok %s / %s n_rest %s vs %s total %s vs %s solved %s" % (
+                t["lcm_rows"].tolist() == rows.tolist(), t["lcm_cols"].tolist() == cols.tolist(), len(t["lcm_rows"]), len(rows), t["lcm_min_val"], lm,
+                t["kept_cabs"].tolist() == keep_c.tolist(), t["kept_dems"].tolist() == keep_d.tolist(), t["n_rest"], n2, t["total"], tot, t["solved"]), flush=True)
     else:
         n = int(rng.integers(2, 1200))
         world = int(rng.integers(1, 9))
