@@ -1592,10 +1592,10 @@ int td::lcm_stands(int n_s, int n_d, const int32_t *d_cab_to, const int32_t *d_d
     const LcmOut *ho = (const LcmOut *)c.pinned;
     const int k = ho->n_pairs;
     const int32_t lm = ho->last_min;
-    if (k > 0) {
-        TD_HIP(hipMemcpyAsync(rows, d_rows, sizeof(int32_t) * (size_t)k, hipMemcpyDeviceToHost, c.stream));
-        TD_HIP(hipMemcpyAsync(cols, d_cols, sizeof(int32_t) * (size_t)k, hipMemcpyDeviceToHost, c.stream));
-    }
+    // (the pair list stays on the device — c.lcm_b: rows, then cols, n entries each — for the caller's shrink kernel; td_tick
+    // brings it home in its one pinned read-back at the end: two copies into pageable host arrays here cost ~20 us each)
+    (void)rows;
+    (void)cols;
     *n_pairs = k;
     *last_min = lm;
     *ok = 1;

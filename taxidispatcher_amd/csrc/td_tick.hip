@@ -101,7 +101,7 @@ extern "C" int td_tick(const int32_t *cab_to, int n_s, const int32_t *dem_from, 
     int rc;
     if ((rc = ensure(t.pos, sizeof(int32_t) * 4 * (size_t)n + (dist && !is_device_ptr(dist) ? sizeof(int32_t) * (size_t)S * S : 0)))) return rc;
     if ((rc = ensure(t.keep, sizeof(int32_t) * (2 * (size_t)n + 4)))) return rc;
-    const size_t pin_need = sizeof(int32_t) * (2 * (size_t)n + 4);
+    const size_t pin_need = sizeof(int32_t) * (4 * (size_t)n + 8);   // kept cabs, kept requests, 2 counts (+2), then the pair list (rows, cols) of the stands LCM
     if (t.pin_cap < pin_need) {
         if (t.pin) (void)hipHostFree(t.pin);
         t.pin = nullptr;
@@ -200,6 +200,9 @@ extern "C" int td_tick(const int32_t *cab_to, int n_s, const int32_t *dem_from, 
     if (kc < 0 || kd < 0) return fail(TD_EINTERNAL, "td_tick: more LCM pairs than cabs or requests");
     int32_t *hp = (int32_t *)t.pin;
     TD_HIP(hipMemcpyAsync(hp, d_keep_c, sizeof(int32_t) * (2 * (size_t)n + 2), hipMemcpyDeviceToHost, c.stream));
+    int32_t *hpairs = hp + 2 * (size_t)n + 4;
+    if (on_stands && k > 0)   // the stands LCM left its pair list on the device: home with the same pinned read-back
+        TD_HIP(hipMemcpyAsync(hpairs, d_rows, sizeof(int32_t) * 2 * (size_t)n, hipMemcpyDeviceToHost, c.stream));
     *n_rest = n2;
     // Simulator.java:188-189: when the LCM ended on big_cost ("no input for the solver; continue") the reference does
     // not call the solver in this tick.  The pairs, LCM_min_val and the kept lists are reported, row_to_col and
@@ -213,6 +216,10 @@ extern "C" int td_tick(const int32_t *cab_to, int n_s, const int32_t *dem_from, 
         TD_HIP(hipStreamSynchronize(c.stream));
     }
     if (hp[2 * (size_t)n] != kc || hp[2 * (size_t)n + 1] != kd) return fail(TD_EINTERNAL, "td_tick: shrink kept %d / %d, expected %d / %d", hp[2 * (size_t)n], hp[2 * (size_t)n + 1], kc, kd);
+    if (on_stands && k > 0) {
+        memcpy(lcm_rows, hpairs, sizeof(int32_t) * (size_t)k);
+        memcpy(lcm_cols, hpairs + n, sizeof(int32_t) * (size_t)k);
+    }
     if (kept_cabs) memcpy(kept_cabs, hp, sizeof(int32_t) * (size_t)kc);
     if (kept_dems) memcpy(kept_dems, hp + n, sizeof(int32_t) * (size_t)kd);
     return TD_OK;
