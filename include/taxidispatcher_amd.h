@@ -111,6 +111,18 @@ TD_API int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_t *t
  * returns the previous setting. */
 TD_API int td_set_line_metric(int on);
 
+/* ---- handle-scoped solvers ("the library must be re-entrant per handle") -----------------------------
+ * td_assign / td_build_assign solve in the library's default workspace.  A td_solver owns a workspace of its own (grow-only,
+ * released by td_solver_destroy), so one process can keep several — e.g. one sized for N = 65 536 and one for ticks — without
+ * one call regrowing what the other needs.  Same arguments, results and errors as td_assign / td_build_assign; calls are
+ * synchronous and one at a time, like the reference (strictly single-threaded). */
+typedef struct td_solver td_solver;
+TD_API int td_solver_create(td_solver **out);
+TD_API int td_solver_destroy(td_solver *h);
+TD_API int td_solver_assign(td_solver *h, int n, const int32_t *cost, int32_t *row_to_col, int64_t *total, int64_t *dual_bound);
+TD_API int td_solver_build_assign(td_solver *h, const int32_t *cab_to, int n_s, const int32_t *dem_from, int n_d, const int32_t *dist, int S,
+                                  int32_t fill, int32_t threshold, int32_t *row_to_col, int64_t *total, int64_t *dual_bound);
+
 /* ---- API #1 of the reference in ONE call: cost build + optimal assignment --------------------------------------
  * What procedure.py:5-29, greedy_opt.py:102-118 and simulate.py:36-53 expose: solve(distances, demand, cabs) builds the cost
  * matrix (td_cost_build's positional rule: cost[i][j] = dist[cab_to[i]][dem_from[j]] if below `threshold`, else `fill`;

@@ -5,10 +5,10 @@ kernels behind a C ABI (include/taxidispatcher_amd.h).  See DESIGN.md / INTEGRAT
 """
 from . import _ffi
 from ._ffi import TdError, init, shutdown
-from .dispatch import (BIG_COST, LCM, LCM_heuristic, LCM_simulator, assign, build_assign, calculate_cost, calculate_cost_by_id,
+from .dispatch import (BIG_COST, LCM, Solver, LCM_heuristic, LCM_simulator, assign, build_assign, calculate_cost, calculate_cost_by_id,
                        combined, cost_build, count_sum, expand_x, filter_out, find_pool, find_pool_n, last_stats, merge_pools,
                        procedure_solve, set_line_metric, solve, solve_cost, tick)
 
-__all__ = ["TdError", "init", "shutdown", "BIG_COST", "LCM", "LCM_heuristic", "LCM_simulator", "assign", "build_assign",
+__all__ = ["TdError", "init", "shutdown", "BIG_COST", "LCM", "Solver", "LCM_heuristic", "LCM_simulator", "assign", "build_assign",
            "calculate_cost", "calculate_cost_by_id", "combined", "cost_build", "count_sum", "expand_x", "filter_out", "find_pool",
            "find_pool_n", "merge_pools", "last_stats", "procedure_solve", "set_line_metric", "solve", "solve_cost", "tick"]

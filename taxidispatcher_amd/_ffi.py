@@ -32,6 +32,12 @@ SIGNATURES = {
     "td_assign": (ctypes.c_int, [ctypes.c_int, c_i32p, c_i32p, ctypes.POINTER(ctypes.c_int64),
                                  ctypes.POINTER(ctypes.c_int64)]),
     "td_set_line_metric": (ctypes.c_int, [ctypes.c_int]),
+    "td_solver_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
+    "td_solver_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "td_solver_assign": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_i32p, c_i32p, ctypes.POINTER(ctypes.c_int64),
+                                        ctypes.POINTER(ctypes.c_int64)]),
+    "td_solver_build_assign": (ctypes.c_int, [ctypes.c_void_p, c_i32p, ctypes.c_int, c_i32p, ctypes.c_int, c_i32p, ctypes.c_int, ctypes.c_int32,
+                                              ctypes.c_int32, c_i32p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "td_build_assign": (ctypes.c_int, [c_i32p, ctypes.c_int, c_i32p, ctypes.c_int, c_i32p, ctypes.c_int, ctypes.c_int32, ctypes.c_int32,
                                        c_i32p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "td_expand_x": (ctypes.c_int, [ctypes.c_int, c_i32p, ctypes.c_void_p]),

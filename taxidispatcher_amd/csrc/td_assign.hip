@@ -3122,6 +3122,7 @@ namespace {
 
 using Solver = td_shard;
 Solver g_default;  // td_assign's workspace, kept across calls
+Solver *g_active = &g_default;   // the workspace the next td_assign / td_build_assign call solves in (a td_solver_* call switches it for its duration)
 
 int sv_prepare(Solver &sv, int n, int row0, int nrows, const int32_t *cost)
 {
@@ -4030,7 +4031,7 @@ int td::build_assign_device(const int32_t *d_cab, int n_s, const int32_t *d_dem,
 {
     read_tunables();
     const int n = std::max(n_s, n_d);
-    Solver &sv = g_default;
+    Solver &sv = *g_active;
     int rc;
     if ((rc = ensure(sv.misc, 4096))) return rc;
     const int const_cols = n - n_d, const_rows = n - n_s;
@@ -4064,7 +4065,17 @@ int td::build_assign_device(const int32_t *d_cab, int n_s, const int32_t *d_dem,
 // =====================================================================================
 // td_assign
 // =====================================================================================
+namespace {
+int assign_impl(Solver &sv, int n, const int32_t *cost, int32_t *row_to_col, int64_t *total, int64_t *dual_bound);
+}  // namespace
+
 extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_t *total, int64_t *dual_bound)
+{
+    return assign_impl(*g_active, n, cost, row_to_col, total, dual_bound);
+}
+
+namespace {
+int assign_impl(Solver &sv, int n, const int32_t *cost, int32_t *row_to_col, int64_t *total, int64_t *dual_bound)
 {
     // the hint of td_tick is for THIS call only, whatever way the call ends (an early return left it for the
     // next, unrelated call)
@@ -4081,7 +4092,6 @@ extern "C" int td_assign(int n, const int32_t *cost, int32_t *row_to_col, int64_
     }
     if (!cost || !row_to_col) return fail(TD_EINVAL, "null array");
     if (n >= (1 << ROW_BITS) - 1) return fail(TD_ERANGE, "n=%d exceeds the packed bid key", n);
-    Solver &sv = g_default;
     sv.skip = nullptr;
     sv.fused_t = false;
     sv.fused8 = false;
@@ -4502,6 +4512,49 @@ restart:
     return TD_OK;
 }
 
+}  // namespace
+
+// ---- handle-scoped solvers ("re-entrant per handle"): a td_solver owns its grow-only workspace, so a process can
+// keep, say, one sized for N = 65 536 and one for ticks side by side; calls stay synchronous and one at a time, like the
+// reference (td_assign itself is the solver of the library's own default handle)
+struct td_solver {
+    td_shard ws;
+};
+
+extern "C" int td_solver_create(td_solver **out)
+{
+    TD_REQUIRE_INIT();
+    if (!out) return fail(TD_EINVAL, "null out");
+    *out = new td_solver();
+    return TD_OK;
+}
+
+extern "C" int td_solver_destroy(td_solver *h)
+{
+    if (!h) return TD_OK;
+    if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
+    h->ws.free_all();
+    delete h;
+    return TD_OK;
+}
+
+extern "C" int td_solver_assign(td_solver *h, int n, const int32_t *cost, int32_t *row_to_col, int64_t *total, int64_t *dual_bound)
+{
+    if (!h) return fail(TD_EINVAL, "null solver");
+    return assign_impl(h->ws, n, cost, row_to_col, total, dual_bound);
+}
+
+extern "C" int td_solver_build_assign(td_solver *h, const int32_t *cab_to, int n_s, const int32_t *dem_from, int n_d, const int32_t *dist, int S,
+                                      int32_t fill, int32_t threshold, int32_t *row_to_col, int64_t *total, int64_t *dual_bound)
+{
+    if (!h) return fail(TD_EINVAL, "null solver");
+    Solver *was = g_active;
+    g_active = &h->ws;
+    const int rc = td_build_assign(cab_to, n_s, dem_from, n_d, dist, S, fill, threshold, row_to_col, total, dual_bound);
+    g_active = was;
+    return rc;
+}
+
 extern "C" int td_build_assign(const int32_t *cab_to, int n_s, const int32_t *dem_from, int n_d, const int32_t *dist, int S, int32_t fill,
                                int32_t threshold, int32_t *row_to_col, int64_t *total, int64_t *dual_bound)
 {
@@ -4517,7 +4570,7 @@ extern "C" int td_build_assign(const int32_t *cab_to, int n_s, const int32_t *de
     if ((n_s && !cab_to) || (n_d && !dem_from) || !row_to_col) return fail(TD_EINVAL, "null array");
     if (dist && S <= 0) return fail(TD_EINVAL, "dist given but S=%d", S);
     // the (small) position arrays and a host distance table: once on the device, in a buffer of the solver's workspace
-    Solver &sv = g_default;
+    Solver &sv = *g_active;
     int rc;
     const size_t words = (size_t)n_s + n_d + ((dist && !is_device_ptr(dist)) ? (size_t)S * S : 0) + 16;
     if ((rc = ensure(sv.gpos, sizeof(int32_t) * words))) return rc;

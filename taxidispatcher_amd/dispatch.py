@@ -138,6 +138,55 @@ def build_assign(cab_to, dem_from, distances=None, fill=BIG_COST, threshold=-1, 
     return n, r2c, int(total.value)
 
 
+class Solver:
+    """A handle-scoped solver (td_solver_*): its own grow-only workspace on the GPU, same calls and answers as assign() /
+    build_assign().  Several can live in one process (re-entrant per handle); calls stay synchronous."""
+
+    def __init__(self):
+        self.lib = _ffi.lib()
+        h = ctypes.c_void_p()
+        _ffi.check(self.lib.td_solver_create(ctypes.byref(h)))
+        self.h = h
+
+    def assign(self, cost, n=None, want_dual=False):
+        if isinstance(cost, np.ndarray) or not hasattr(cost, "data_ptr"):
+            cost = _ffi.as_i32(cost)
+        else:
+            _require_i32(cost, "cost")
+        if n is None:
+            n = int(cost.shape[0])
+        r2c = np.empty(n, np.int32)
+        total, dual = ctypes.c_int64(0), ctypes.c_int64(0)
+        _ffi.check(self.lib.td_solver_assign(self.h, n, _ffi.addr(cost), _ffi.addr(r2c), ctypes.byref(total),
+                                             ctypes.byref(dual) if want_dual else None))
+        return (r2c, int(total.value), int(dual.value)) if want_dual else (r2c, int(total.value))
+
+    def build_assign(self, cab_to, dem_from, distances=None, fill=BIG_COST, threshold=-1, want_dual=False):
+        cab = cab_to if hasattr(cab_to, "data_ptr") else _ffi.as_i32(cab_to)
+        dem = dem_from if hasattr(dem_from, "data_ptr") else _ffi.as_i32(dem_from)
+        n_s, n_d = int(cab.shape[0]), int(dem.shape[0])
+        n = max(n_s, n_d)
+        dptr, S, keep = _dist_arg(distances)
+        r2c = np.empty(n, np.int32)
+        total, dual = ctypes.c_int64(0), ctypes.c_int64(0)
+        _ffi.check(self.lib.td_solver_build_assign(self.h, _ffi.addr(cab) if n_s else None, n_s, _ffi.addr(dem) if n_d else None, n_d, dptr, S,
+                                                   int(fill), int(threshold), _ffi.addr(r2c) if n else None, ctypes.byref(total),
+                                                   ctypes.byref(dual) if want_dual else None))
+        del keep
+        return (n, r2c, int(total.value), int(dual.value)) if want_dual else (n, r2c, int(total.value))
+
+    def close(self):
+        if self.h:
+            self.lib.td_solver_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def expand_x(n, row_to_col):
     """row_to_col -> the reference's n*n 0/1 vector, index n*cab + cust (solver.py:36-39)."""
     x = np.zeros(n * n, np.uint8)

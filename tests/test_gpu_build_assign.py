@@ -97,3 +97,32 @@ def test_procedure_solve_goes_through_td_build_assign(td):
     r2c = np.argmax(x.reshape(n, n), axis=1)
     assert sorted(r2c.tolist()) == list(range(n))
     assert int(cost[np.arange(n), r2c].astype(np.int64).sum()) == oracle.assign(cost)[0]
+
+
+def test_two_handle_scoped_solvers_side_by_side(td):
+    """SURVEY 8b "re-entrant per handle": two td_solver handles with workspaces of their own, used alternately on models of
+    different sizes and widths (1-byte perf.jl rows, 4-byte padded ticks, td_build_assign's fused path), give what td_assign
+    gives on the same inputs; destroying one leaves the other working"""
+    rng = np.random.default_rng(4)
+    big = rng.integers(10, 41, (3000, 3000)).astype(np.int32)
+    cab_to, dem_from = rng.integers(0, 50, 900), rng.integers(0, 50, 300)
+    _, tick_cost = td.cost_build(cab_to, dem_from, None, fill=BIG, threshold=10)
+    ref_big = td.assign(big, want_dual=True)
+    ref_tick = td.assign(tick_cost, want_dual=True)
+    a, b = td.Solver(), td.Solver()
+    try:
+        for _ in range(2):
+            ra = a.assign(big, want_dual=True)
+            rb = b.assign(tick_cost, want_dual=True)
+            rc = a.build_assign(cab_to, dem_from, None, fill=BIG, threshold=10, want_dual=True)
+            assert ra[1] == ra[2] == ref_big[1] and np.array_equal(ra[0], ref_big[0])
+            assert rb[1] == rb[2] == ref_tick[1] and np.array_equal(rb[0], ref_tick[0])
+            assert rc[2] == rc[3] == ref_tick[1] and sorted(rc[1].tolist()) == list(range(900))
+        a.close()
+        rb = b.assign(big, want_dual=True)      # the other handle grows to the larger model
+        assert rb[1] == rb[2] == ref_big[1] and np.array_equal(rb[0], ref_big[0])
+    finally:
+        a.close()
+        b.close()
+    again = td.assign(big, want_dual=True)      # the default workspace was never touched by the handles
+    assert again[1] == ref_big[1] and np.array_equal(again[0], ref_big[0])
