@@ -303,16 +303,18 @@ TD_API int td_shard_row_to_col(td_shard *s, int32_t *r2c_local);
  * device memory: fits / ran / free rows left / constant rows / range, the owners of its column slice, the
  * constant-row flags of its rows), the caller all-gathers the segments in rank order, td_shard_state_import fills in
  * the other slices (owners, owned bits, the replicated constant-row mask of td_shard_const_rows) and returns
- * summary[0..4] = {all ranks fit, all ran phase A, free rows left in total, constant rows, largest row range}.
+ * summary[0..5] = {all ranks fit, all ran phase A, free rows left in total, constant rows, largest row range, rank 0's segment
+ * word 6 (free for the caller: solve_sharded carries the line-metric attempt's plausibility word there)}.
  * The ordinary rounds (td_shard_bid / _apply / _rounds) and td_shard_finish take what is still free; when
  * summary[2] == 0 the solve is complete.  td_assign starts the same way for n >= 12 288 (td_set_blocks),
  * so a sharded run and td_assign with the same block count stay bit-identical. */
+TD_API int td_shard_compress_spec(td_shard *s);   /* the 1-byte compress pass without waiting for its width flag (it travels in the segment) */
 TD_API int td_shard_blocks_pending(td_shard *s);
 TD_API int td_shard_phase_a(td_shard *s);
 TD_API int td_shard_state_words(td_shard *s, int rows_per_shard);
 TD_API int td_shard_state_export(td_shard *s, int rows_per_shard, int fits, int32_t *seg /* device */);
 TD_API int td_shard_state_import(td_shard *s, int world, int rank, int rows_per_shard, const int32_t *all /* device */,
-                                 int64_t *summary5 /* host */);
+                                 int64_t *summary6 /* host, 6 words */);
 /* summary[2] == 0 with constant rows in the model: every rank places them itself from the replicated owner[] and mask
  * (k-th constant row <- k-th column nobody owns, what td_shard_finish does on its rank) — no finisher, no exchange */
 TD_API int td_shard_place_const(td_shard *s);

@@ -4663,6 +4663,17 @@ int td_shard_compress(td_shard *s, int bytes_per_cell, int *fits)
     return rc;
 }
 
+// The 1-byte attempt of the block-local start WITHOUT waiting for its width flag (as td_assign speculates): the flag stays on
+// the device, every later kernel of the attempt exits on it, td_shard_state_export reports it in the segment's word 0 and the
+// ranks learn it from the one all-gather.  Saves the rank a host synchronisation in front of phase A.
+int td_shard_compress_spec(td_shard *s)
+{
+    TD_REQUIRE_INIT();
+    if (!s) return fail(TD_EINVAL, "null shard");
+    bool f = false;
+    return sv_compress(*s, 1, &f, true);
+}
+
 // Constant rows (dummy cabs of a padded model) sit out the sharded solve as they do in td_assign: between
 // td_shard_compress and td_shard_begin every rank writes its constant rows into a zeroed mask of n ints (set = 0),
 // the caller SUM-all-reduces it and hands the result back (set = 1).  The rows then never bid, the finisher's rank
@@ -4738,7 +4749,7 @@ __global__ void k_state_export(int nrows, int rps, int col_lo, int fits, int ran
         if (t == 3) v = ctl[CTL_NCONST];
         if (t == 4) v = ctl[CTL_RSEEN];
         if (t == 5) v = ctl[CTL_RSEEN + 1];
-        seg[t] = v;
+        if (t != 6) seg[t] = v;   // word 6 is the caller's (written before or after this kernel, on the same stream)
     }
     if (t < rps) {
         seg[16 + t] = (ran && t < nrows) ? owner[col_lo + t] : -1;
@@ -4766,6 +4777,7 @@ __global__ void k_state_import(int n, int world, int rps, int words, int own_ran
         summary[2] = left;
         summary[3] = nconst;
         summary[4] = range;
+        summary[5] = all[6];   // rank 0's spare word 6: the caller's own (solve_sharded: the line-metric attempt's plausibility word)
     }
     if (t < n) {
         const int r = t / rps, k = t - r * rps;
@@ -4815,9 +4827,9 @@ int td_shard_state_import(td_shard *s, int world, int rank, int rows_per_shard, 
                                                             (int32_t *)s->price.p, (int *)s->cmask.p, sum_dev);
     }
     TD_HIP(hipGetLastError());
-    TD_HIP(hipMemcpyAsync(c.pinned, sum_dev, 5 * sizeof(long long), hipMemcpyDeviceToHost, c.stream));
+    TD_HIP(hipMemcpyAsync(c.pinned, sum_dev, 6 * sizeof(long long), hipMemcpyDeviceToHost, c.stream));
     TD_HIP(hipStreamSynchronize(c.stream));
-    for (int k = 0; k < 5; k++) summary5[k] = ((const long long *)c.pinned)[k];
+    for (int k = 0; k < 6; k++) summary5[k] = ((const long long *)c.pinned)[k];
     s->have_cmask = true;
     s->defer_const = g_defer_const && !g_solver_eps;
     return TD_OK;

@@ -248,6 +248,10 @@ class HipShard:
     def blocks_start(self, on=True):
         _ffi.check(self.lib.td_shard_options(self.h, 3 if on else 1))
 
+    def compress_spec(self):
+        """the 1-byte compress pass of the block-local start without waiting for its width flag (it travels in the segment)"""
+        _ffi.check(self.lib.td_shard_compress_spec(self.h))
+
     def blocks_pending(self):
         return bool(self.lib.td_shard_blocks_pending(self.h))
 
@@ -269,9 +273,9 @@ class HipShard:
 
     def state_import(self, world, rank, rps, allseg):
         """the gathered segments -> the other slices' owners, the constant-row mask; returns the summary"""
-        out = (ctypes.c_int64 * 5)()
+        out = (ctypes.c_int64 * 6)()
         _ffi.check(self.lib.td_shard_state_import(self.h, int(world), int(rank), int(rps), allseg.data_ptr(), out))
-        return {"fit": bool(out[0]), "ran": bool(out[1]), "left": int(out[2]), "nconst": int(out[3]), "range": int(out[4])}
+        return {"fit": bool(out[0]), "ran": bool(out[1]), "left": int(out[2]), "nconst": int(out[3]), "range": int(out[4]), "word6": int(out[5])}
 
     # -- constant rows sit out the solve (td_shard_const_rows)
     def const_mask(self):
@@ -446,7 +450,18 @@ def _solve_sharded(shard, dist, rounds, want_dual, use_ipc):
     # 0. the sorted matching first (td_assign's order): O(n) exchanged, one local pass over the rows; accepted only
     #    when every rank's rows certify it (total == dual bound by construction)
     solve_sharded.last_path = "auction"
-    if hasattr(shard, "line_phase") and n >= 2 and os.environ.get("TD_LINE", "1") != "0":
+    defer0 = hasattr(shard, "const_mask") and os.environ.get("TD_DEFER_CONST", "1") != "0"
+    can_blocks0 = shard.blocks_ok(n, world) if hasattr(shard, "blocks_ok") else blocks_ok(n, world)
+    blocks_first = (defer0 and hasattr(shard, "phase_a") and os.environ.get("TD_SHARD_BLOCKS", "1") != "0" and can_blocks0 and
+                    hasattr(shard, "compress_spec"))
+    want_line = hasattr(shard, "line_phase") and n >= 2 and os.environ.get("TD_LINE", "1") != "0"
+    line_ws0 = None
+    if want_line and blocks_first:
+        # the block-local start follows: the line attempt's first test (do rows 0 and 1 look like a line metric at all) is queued
+        # here, its verdict rides in the one all-gather below instead of an exchange + a read-back of its own
+        line_ws0 = shard.line_ws()
+        shard.line_phase(0, line_ws0)
+    elif want_line:
         got = line_sharded([shard], dist)
         solve_sharded.last_path = "line" if got is not None else "auction"
         if got is not None:
@@ -462,12 +477,26 @@ def _solve_sharded(shard, dist, rounds, want_dual, use_ipc):
     can_blocks = shard.blocks_ok(n, world) if hasattr(shard, "blocks_ok") else blocks_ok(n, world)
     if defer and hasattr(shard, "phase_a") and os.environ.get("TD_SHARD_BLOCKS", "1") != "0" and can_blocks:
         shard.blocks_start(True)
-        fits = shard.compress(1)
+        if hasattr(shard, "compress_spec"):
+            shard.compress_spec()      # no wait for the width flag: it is word 0 of the segment
+            fits = True
+        else:
+            fits = shard.compress(1)
         if fits and shard.blocks_pending():
             shard.phase_a()
         seg = shard.state_segment(rps, fits)
+        if line_ws0 is not None:
+            seg[6:7].copy_(line_ws0[4:5])   # LC_PLAUS of the rank that owns row 0 (zero elsewhere)
         allseg = all_gather_cat(dist, seg) if (world > 1 or os.environ.get("TD_SHARD_FORCE_AR")) else seg
         summ = shard.state_import(world, rank, rps, allseg)
+        if line_ws0 is not None and summ.get("word6", 0) != 0:
+            # rows 0 and 1 are compatible with a line metric: the full attempt (four small exchanges, one local pass); the
+            # block-local state stays valid if it is refused after all
+            got = line_sharded([shard], dist)
+            if got is not None:
+                solve_sharded.last_path = "line"
+                total, (r2c,) = got
+                return (r2c, total, total) if want_dual else (r2c, total)
         if summ["fit"] and summ["ran"]:
             left = summ["left"]
             shard.begin(summ["range"])
