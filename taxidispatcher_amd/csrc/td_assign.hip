@@ -215,6 +215,7 @@ long long g_forest_wx = 16; // TD_FOREST_WX     how far above the smallest free-
 int g_blocks = -1;          // TD_BLOCKS        block-local start of the 1-byte attempt (td_blocks.h): diagonal blocks of the matrix; 0: off, -1: by size (td_assign: off below TD_BLOCKS_MIN_N)
 int g_blocks_min_n = 12288; // TD_BLOCKS_MIN_N  smallest n td_assign starts block-locally by itself (perf.jl solve, n = 12 288 / 16 384 / 32 768 / 65 536: 0.61 / 0.76 / 2.26 / 7.5 -> 0.41 / 0.52 / 1.69 / 6.2 ms)
 int g_zs_rounds = 4;        // TD_ZS_ROUNDS     local bidding rounds of phase A after round 0
+int g_zs_sep = 0;           // TD_ZS_SEP        rows of <= 16 384 columns: round 0 of phase A as its own launch behind the plain compress pass.  OFF: measured slower (td_assign n = 16 384 0.487 -> 0.543 ms: the plain 256 x 16 pass takes 0.29 ms in this sequence, the pass that also writes the bids 0.243)
 int g_hop_passes = 2;       // TD_HOP_PASSES    two-hop passes at the end of phase A (the second one takes the rows the first pass's greedy left: 4 of 183 at n = 16 384)
 int g_hop_max_rows = HOP_FMAX;   // TD_HOP_MAX_ROWS  a block with more free rows than this is left to the rounds
 int g_hop_global = 1;       // TD_HOP_GLOBAL    td_assign: one two-hop pass over the whole matrix after phase A
@@ -294,6 +295,7 @@ void read_tunables()
     if (const char *e = getenv("TD_BLOCKS")) g_blocks = std::max(-1, std::min(HOP_BMAX, atoi(e)));
     if (const char *e = getenv("TD_BLOCKS_MIN_N")) g_blocks_min_n = std::max(0, atoi(e));
     if (const char *e = getenv("TD_ZS_ROUNDS")) g_zs_rounds = std::max(0, std::min(32, atoi(e)));
+    if (const char *e = getenv("TD_ZS_SEP")) g_zs_sep = atoi(e) != 0;
     if (const char *e = getenv("TD_HOP_PASSES")) g_hop_passes = std::max(0, std::min(8, atoi(e)));
     if (const char *e = getenv("TD_HOP_MAX_ROWS")) g_hop_max_rows = std::max(1, atoi(e));
     if (const char *e = getenv("TD_HOP_GLOBAL")) g_hop_global = atoi(e) != 0;
@@ -3103,7 +3105,9 @@ struct td_shard {
     Buf gpos;                  // td_build_assign's position arrays / distance table on the device
     bool tick_sized = false;   // td_tick's remainder (hinted, n < 2048): the rounds leave a dozen rows, the serial workgroup is through before a speculative batch + its commit are — no read-back of the free-row count to decide that
     int zs_V = 0;              // diagonal blocks of the whole matrix the 1-byte attempt may start in (0: off)
-    bool zs_done = false;      // the compress pass wrote the zero-slice bids of phase A's round 0: sv_phase_a is due
+    bool zs_done = false;      // the compress pass prepared the block-local start (wrote the zero-slice bids of phase A's round 0, or left them to k_zs_bid: zs_round0): sv_phase_a is due
+    bool zs_round0 = false;    // ... round 0 of phase A is still to be bid (rows of <= 16 384 columns: the plain compress pass + one k_zs_bid round over 1/8 of every row beat the pass that also scans for the bids, 216 + ~10 against 243 us)
+    bool began = false;        // the state (prices, owners, row_to_col, bid keys) has been initialised for the current compressed copy
     bool state_ready = false;  // sharded solve: the state was initialised in front of the compress pass and phase A has run on it (td_shard_begin must not redo it)
     Buf ob, esc, hop, hoptab;  // owned bytes per column, escape masks per row, HopCtl, the two-hop tables
     Buf core, core_n, core_t, core_need;   // sparse core of the warm start (td_core_warm.h): lists, their lengths, the smallest value outside, the rows that need their dense row
@@ -3165,6 +3169,8 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
     sv.bid0_done = false;
     sv.state_ready = false;
     sv.zs_done = false;
+    sv.zs_round0 = false;
+    sv.began = false;
     if (nrows > 0) {
         const int nq = n / 4;
         CT *cc = (CT *)sv.cc.p;
@@ -3180,9 +3186,18 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
             const int rpb = n / sv.zs_V;
             if (sv.row0 % rpb == 0 && nrows % rpb == 0 && nrows / rpb <= HOP_BMAX) zs_rpb = rpb;
         }
+        // block-local start of rows that fit the 256-thread pass (n <= 16 384): round 0 of phase A as its own k_zs_bid launch
+        // (it reads 1/V of every row: 32 MB at n = 16 384) behind the PLAIN pass, which is 27 us faster than the one that
+        // scans the narrow words for the bids; wider rows keep the fused pass (their plain pass is no faster: spills)
+        const bool zs_sep = zs_rpb > 0 && g_zs_sep && nq <= 256 * 16;
+        if (zs_sep) {
+            sv.zs_done = true;
+            sv.zs_round0 = true;
+        }
+        const bool bid0_kernel = bid0 && !zs_sep;
         static const int gbm = getenv("TD_BID0_GRID") ? atoi(getenv("TD_BID0_GRID")) : 0;
         const int gb = std::max(1, std::min(nrows, c.n_cu * (gbm > 0 ? gbm : std::max(1, g_cgrid / 2))));   // 512-thread workgroups of the BID0 pass
-        if (bid0) {
+        if (bid0_kernel) {
             using PT = typename Tr<CT>::PT;
             const int npad = nchunks * E;
             const PT padkey = (PT)(Tr<CT>::BIG << 1) | (PT)1;
@@ -3204,7 +3219,7 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
             else if (nq <= 512) { TD_CR(2); }
             else if (nq <= 1024) { TD_CR(4); }
             else if (nq <= 2048) { TD_CR(8); }
-            else if (bid0) {
+            else if (bid0_kernel) {
                 // 512 threads x 8 pieces: half the row registers per thread, so that the zero-byte scan fits without giving up waves
                 if constexpr (sizeof(CT) == 1) {
                     static const int shape = getenv("TD_BID0_SHAPE") ? atoi(getenv("TD_BID0_SHAPE")) : 0;
@@ -3227,7 +3242,7 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
 #undef TD_CR
         } else if (g_creg && vec && nq <= 1024 * 16) {
             const int g4 = std::max(1, std::min(nrows, c.n_cu * 2));
-            if (bid0) {
+            if (bid0_kernel) {
                 if constexpr (sizeof(CT) == 1)
                 {
                     k_compress_reg<CT, 16, 1024, true><<<g4, 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
@@ -3382,6 +3397,9 @@ int sv_hop_t(Solver &sv, int rpb, int ncols_blk, int col_lo, int nb, bool window
 // Phase A of a 1-byte attempt whose compress pass wrote the zero-slice bids (sv.zs_done): everything local to this
 // shard's diagonal blocks, no price moves.  Leaves the ordinary state (owner / r2c / packed prices with the owned bit)
 // for the global rounds; the free rows it left are counted in HopCtl::left.
+template <typename CT>
+int sv_begin_t(Solver &sv);
+
 int sv_phase_a(Solver &sv, int hop_passes)
 {
     Ctx &c = ctx();
@@ -3399,7 +3417,13 @@ int sv_phase_a(Solver &sv, int hop_passes)
         k_zs_assign<<<ga, 256, 0, c.stream>>>(col_lo, col_hi, nrows, sv.row0, bid, (int32_t *)sv.price.p, (int *)sv.owner.p, (int *)sv.r2c.p,
                                               (uint8_t *)sv.ob.p, ctl);
     };
-    assign();   // round 0: the bids came out of the compress pass
+    if (sv.zs_round0) {   // round 0 as its own launch behind the plain compress pass (the same bids as the fused pass writes, bit for bit)
+        if (!sv.began && (rc = sv_begin_t<uint8_t>(sv))) return rc;   // (a shard: td_shard_begin comes after the exchange)
+        k_zs_bid<<<std::min(nrows, c.n_cu * 16), 256, 0, c.stream>>>(nrows, sv.row0, sv.nchunks, rpb, (const uint8_t *)sv.cc.p,
+                                                                     (const uint8_t *)sv.ob.p, (const int *)sv.r2c.p, bid, ctl, 0, 0);
+        sv.zs_round0 = false;
+    }
+    assign();   // round 0
     for (int r = 1; r <= g_zs_rounds; r++) {
         k_zs_bid<<<std::min(nrows, c.n_cu * 16), 256, 0, c.stream>>>(nrows, sv.row0, sv.nchunks, rpb, (const uint8_t *)sv.cc.p,
                                                                      (const uint8_t *)sv.ob.p, (const int *)sv.r2c.p, bid, ctl, r, g_tie_evict);
@@ -3433,6 +3457,7 @@ int sv_begin_t(Solver &sv)
         (unsigned long long *)sv.bid.p, (int *)sv.misc.p, sv.defer_const ? (const int *)sv.rconst.p : nullptr, sv.probe);
     TD_HIP(hipMemsetAsync((char *)sv.misc.p + 1024, 0, 16, c.stream));
     TD_HIP(hipGetLastError());
+    sv.began = true;
     return TD_OK;
 }
 
