@@ -191,6 +191,7 @@ int g_warm_groups = 32;     // TD_WARM_GROUPS   groups of 8 rounds per phase at 
 int g_warm_cut = 64;        // TD_WARM_CUT      a phase ends when <= n / this rows are free (0: none)
 int g_warm_min_range = 256; // TD_WARM_MIN_RANGE rows narrower than this are never warmed
 int g_warm_minfree = 32;    // TD_WARM_MINFREE  free rows after the eps = 0 rounds below which the finisher is cheaper
+int g_warm_min_n = 512;     // TD_WARM_MIN_N    no warm start for smaller models
 int g_sapx = 1;             // TD_SAPX          cooperative multi-workgroup serial finisher (k_sapx)
 int g_sapx_min = 8;         // TD_SAPX_MIN      fewest workgroups (256 chunks each) for which it is used
 int g_sapx_slim_chunks = INT_MAX; // TD_SAPX_SLIM  1- / 2-byte rows with at least this many 16-byte chunks: 64-thread column slices in k_sapx.  OFF: measured at n = 65 536 (perf.jl rows, 7 searches, 14 steps) 64 slim workgroups take 1.41 ms against 0.71 ms for 16 wide ones — the barrier and the publish phase grow with the workgroup count faster than the relax shrinks
@@ -255,6 +256,7 @@ void read_tunables()
     if (const char *e = getenv("TD_WARM_CUT")) g_warm_cut = std::max(0, atoi(e));
     if (const char *e = getenv("TD_WARM_MIN_RANGE")) g_warm_min_range = std::max(1, atoi(e));
     if (const char *e = getenv("TD_WARM_MINFREE")) g_warm_minfree = std::max(1, atoi(e));
+    if (const char *e = getenv("TD_WARM_MIN_N")) g_warm_min_n = std::max(0, atoi(e));
     if (const char *e = getenv("TD_SAPX_MIN")) g_sapx_min = std::max(1, atoi(e));
     if (const char *e = getenv("TD_SAPX_SLIM")) g_sapx_slim_chunks = std::max(64, atoi(e));
     if (const char *e = getenv("TD_SAPX_ROWS")) g_sapx_rows = std::max(1, atoi(e));
@@ -807,7 +809,7 @@ __global__ __launch_bounds__(LDSP ? 1024 : 256) void k_bid(int n, int nrows, int
             const PT inc = (x == Tr<CT>::KMAX) ? (PT)0 : (PT)((x >> 1) - (bk >> 1));
             const bool owned = (bk & 1) != 0;
             // sampled (every 16th row): 16 384 same-address atomics would cost more than the round
-            if (tied && inc == 0 && (row & 15) == 0) atomicAdd(tied, 1);
+            if (tied && inc == 0 && (n < 1024 || (row & 15) == 0)) atomicAdd(tied, 1);   // (small models: every row, 4 samples of a 60-row model say nothing)
             // A tie on an owned column raises no price.  With tie_evict the row still takes the
             // column (complementary slackness stays exact, the previous owner re-bids next round
             // and usually finds a free tied column); otherwise it is left to the finisher.
@@ -4416,7 +4418,10 @@ restart:
             TD_HIP(hipMemcpyAsync(c.pinned, sv.misc.p, CTL_ALL * sizeof(int), hipMemcpyDeviceToHost, c.stream));
             TD_HIP(hipStreamSynchronize(c.stream));
             const int nfree_now = ((int *)c.pinned)[CTL_NFREE], tied0 = ((int *)c.pinned)[CTL_TIED];
-            wide = !(nfree_now < std::max(g_warm_minfree, n / 64) || (long long)tied0 * 16 * g_warm_tie_div > n);   // tied0 counts every 16th row
+            // tied0 counts every 16th row (every row of a model below 1024).  No warm start below TD_WARM_MIN_N rows: a
+            // thresholded 60 x 60 model ran 800 warm rounds = 8 ms for rows the serial workgroup finishes in microseconds
+            // (tools/r4_outliers.py found it: the 4 sampled rows of so small a model missed its ties)
+            wide = n >= g_warm_min_n && !(nfree_now < std::max(g_warm_minfree, n / 64) || (long long)tied0 * (n < 1024 ? 1 : 16) * g_warm_tie_div > n);
             c.stats[2] = nfree_now;
             hard16 = bpc == 2 && g_u16_redo_free > 0 && nfree_now >= g_u16_redo_free;
         }
