@@ -291,6 +291,9 @@ TD_API int td_shard_finish(td_shard *s, int world, const void *const *shard_ptrs
 TD_API int td_shard_owner(td_shard *s, int32_t *owner, int set);
 TD_API int td_shard_price(td_shard *s, int64_t *price /* n, device */, int set);
 TD_API int td_shard_total(td_shard *s, int64_t *partial_total, int64_t *partial_dual);
+/* the same into three int64 words of DEVICE memory, no host round trip: {partial total, partial dual bound, error / void-attempt
+ * flags}; the caller SUM-all-reduces them and reads them once (word 2 != 0: an error on some rank) */
+TD_API int td_shard_total_dev(td_shard *s, int64_t *out3 /* device */, int want_dual);
 TD_API int td_shard_const_rows(td_shard *s, int32_t *mask_full, int set);
 TD_API int td_shard_options(td_shard *s, int flags);
 TD_API int td_shard_row_to_col(td_shard *s, int32_t *r2c_local);

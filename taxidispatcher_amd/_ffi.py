@@ -90,6 +90,7 @@ SIGNATURES = {
     "td_shard_const_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "td_shard_options": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "td_shard_compress_spec": (ctypes.c_int, [ctypes.c_void_p]),
+    "td_shard_total_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "td_shard_blocks_pending": (ctypes.c_int, [ctypes.c_void_p]),
     "td_shard_phase_a": (ctypes.c_int, [ctypes.c_void_p]),
     "td_shard_state_words": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),

@@ -482,7 +482,10 @@ __device__ __forceinline__ void shape_decide(int n, int *__restrict__ ctl);
 // BID0: the row is in registers with its minimum known, so the bid of round 0 (all prices 0: the first minimum in
 // the row's rotated chunk order, raised by second smallest - smallest) is written here and the round's own pass over
 // the narrow matrix (k_bid, round 0) is not launched — the same key, bit for bit.
-template <typename CT, int VPT, int THREADS, bool BID0 = false>
+// LH > 0: the LAST LH of a thread's VPT 16-byte pieces wait in LDS instead of registers between the load and the store
+// phase (65 536-column rows: 1024 threads x 16 pieces hit the 128-VGPR cap of a 16-wave workgroup and spilled 200 bytes per
+// lane — scratch traffic of the order of the row itself; 8 pieces in registers + 8 x 16 KiB in LDS do not spill).
+template <typename CT, int VPT, int THREADS, bool BID0 = false, int LH = 0>
 __global__ __launch_bounds__(THREADS) void k_compress_reg(
     int n, int nrows, int nchunks, const int32_t *__restrict__ cost, CT *__restrict__ cc, int32_t *__restrict__ rowmin, int *__restrict__ ctl,
     int *__restrict__ rconst, const long long *__restrict__ skip, unsigned long long *__restrict__ bid = nullptr, int row0 = 0,
@@ -548,6 +551,8 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(
             }
         }
     };
+    constexpr int VR = VPT - LH;   // pieces that stay in registers
+    extern __shared__ int4 s_rowh[];   // [LH][THREADS]: every thread reads back what it wrote itself
     for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int4 *s4 = reinterpret_cast<const int4 *>(cost + (int64_t)row * n);
         int4 v[VPT];
@@ -572,6 +577,11 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(
                 mn = min(min(mn, v[k].x), min(v[k].y, min(v[k].z, v[k].w)));
                 mx = max(max(mx, v[k].x), max(v[k].y, max(v[k].z, v[k].w)));
             }
+        }
+        if constexpr (LH > 0) {   // park the upper pieces in LDS: their registers are free for the scan below
+#pragma unroll
+            for (int k = VR; k < VPT; k++)
+                if (k * THREADS + tid < nq) s_rowh[(k - VR) * THREADS + tid] = v[k];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -615,8 +625,14 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(
         for (int k = 0; k < VPT; k++) {
             const int q = k * THREADS + tid;
             if (q < nq) {
-                const uint32_t a = (uint32_t)(v[k].x - mn), b = (uint32_t)(v[k].y - mn), c = (uint32_t)(v[k].z - mn),
-                               d = (uint32_t)(v[k].w - mn);
+                int4 x4;
+                if constexpr (LH > 0) {
+                    if (k >= VR) x4 = s_rowh[(k - VR) * THREADS + tid];
+                    else x4 = v[k];
+                } else
+                    x4 = v[k];
+                const uint32_t a = (uint32_t)(x4.x - mn), b = (uint32_t)(x4.y - mn), c = (uint32_t)(x4.z - mn),
+                               d = (uint32_t)(x4.w - mn);
                 if constexpr (sizeof(CT) == 1) {
                     const uint32_t word = (a & 0xFF) | ((b & 0xFF) << 8) | ((c & 0xFF) << 16) | (d << 24);
                     reinterpret_cast<uint32_t *>(dst)[q] = word;
@@ -2978,6 +2994,15 @@ __global__ __launch_bounds__(256) void k_final(int n, int nrows, int row0, const
     }
 }
 
+__global__ void k_pack_totals(const long long *__restrict__ tot2, const int *__restrict__ ctl, long long *__restrict__ out3)
+{
+    if (threadIdx.x == 0) {
+        out3[0] = tot2[0];
+        out3[1] = tot2[1];
+        out3[2] = (long long)(ctl[CTL_ERR] != 0) + (long long)(ctl[CTL_FLAG] != 0);
+    }
+}
+
 // local row_to_col from the replicated owner[] (after the finisher ran on another shard)
 __global__ void k_r2c_from_owner(int n, int nrows, int row0, const int *__restrict__ owner, int *__restrict__ r2c)
 {
@@ -3244,11 +3269,23 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
 #undef TD_CR
         } else if (g_creg && vec && nq <= 1024 * 16) {
             const int g4 = std::max(1, std::min(nrows, c.n_cu * 2));
+            static const int clds = getenv("TD_CLDS") ? atoi(getenv("TD_CLDS")) : 0;   // pieces per thread parked in LDS (0: all in registers).  Measured at n = 65 536: 0 / 8 / 4 -> 4.046 / 4.032 / 4.637 ms: the 52 bytes per lane the register shape spills are not what holds the pass at 5.3 TB/s of traffic
             if (bid0_kernel) {
                 if constexpr (sizeof(CT) == 1)
                 {
-                    k_compress_reg<CT, 16, 1024, true><<<g4, 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
-                                                                                  sv.row0, defer_r2c, tickets, zs_rpb);
+                    if (clds == 8) {
+                        const int shm = 8 * 1024 * 16;
+                        (void)hipFuncSetAttribute((const void *)k_compress_reg<CT, 16, 1024, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+                        k_compress_reg<CT, 16, 1024, true, 8><<<g4, 1024, shm, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
+                                                                                          sv.row0, defer_r2c, tickets, zs_rpb);
+                    } else if (clds == 4) {
+                        const int shm = 4 * 1024 * 16;
+                        (void)hipFuncSetAttribute((const void *)k_compress_reg<CT, 16, 1024, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+                        k_compress_reg<CT, 16, 1024, true, 4><<<g4, 1024, shm, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
+                                                                                          sv.row0, defer_r2c, tickets, zs_rpb);
+                    } else
+                        k_compress_reg<CT, 16, 1024, true><<<g4, 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
+                                                                                      sv.row0, defer_r2c, tickets, zs_rpb);
                     sv.zs_done = zs_rpb > 0;
                 }
             } else
@@ -5127,6 +5164,25 @@ int td_shard_total(td_shard *s, int64_t *partial_total, int64_t *partial_dual)
     TD_DISPATCH(*s, sv_totals_t, *s, partial_dual != nullptr);
     if (rc) return rc;
     return sv_readback(*s, partial_total, partial_dual, g_max_rounds);
+}
+
+// The same without a host round trip: {partial total, partial dual bound, device-side error / void-attempt flags} as three
+// int64 words in DEVICE memory, queued on the library's stream.  The caller SUM-all-reduces the three words and reads them
+// once (word 2 != 0 on any rank: an error) — td_shard_total's read-back, the host-to-device copy of its result and the
+// read-back of the reduced value were three synchronisations per solve.
+int td_shard_total_dev(td_shard *s, int64_t *out3, int want_dual)
+{
+    TD_REQUIRE_INIT();
+    Ctx &c = ctx();
+    if (!s || !out3) return fail(TD_EINVAL, "null argument");
+    if (!is_device_ptr(out3)) return fail(TD_EINVAL, "td_shard_total_dev: the three words must be device memory");
+    int rc;
+    TD_HIP(hipMemsetAsync((char *)s->misc.p + 1024, 0, 16, c.stream));
+    TD_DISPATCH(*s, sv_totals_t, *s, want_dual != 0);
+    if (rc) return rc;
+    k_pack_totals<<<1, 64, 0, c.stream>>>((const long long *)((const char *)s->misc.p + 1024), (const int *)s->misc.p, (long long *)out3);
+    TD_HIP(hipGetLastError());
+    return TD_OK;
 }
 
 // final column prices (n x int64): get them on the finisher's rank / set them on the others so

@@ -231,6 +231,16 @@ class HipShard:
         _ffi.check(self.lib.td_shard_total(self.h, ctypes.byref(tot), ctypes.byref(dual) if want_dual else None))
         return int(tot.value), int(dual.value)
 
+    def totals_dev(self, want_dual):
+        """{partial total, partial dual bound, error flags} as a device int64 tensor, queued without a host round trip"""
+        t = self.torch.empty(3, dtype=self.torch.int64, device=self.device)
+        if not self.shared_stream:
+            self.torch.cuda.current_stream().synchronize()
+        _ffi.check(self.lib.td_shard_total_dev(self.h, t.data_ptr(), 1 if want_dual else 0))
+        if not self.shared_stream:
+            _ffi.check(self.lib.td_synchronize())
+        return t
+
     def row_to_col(self):
         r = np.empty(self.nrows, np.int32)
         _ffi.check(self.lib.td_shard_row_to_col(self.h, r.ctypes.data if self.nrows else None))
@@ -600,6 +610,16 @@ def _sharded_totals(shard, dist, world, want_dual, finisher_ran):
         if rank != 0:
             shard.set_price(price)
     # 4. totals: each rank sums its own rows
+    if hasattr(shard, "totals_dev"):
+        # the partial sums stay on the device: one SUM all-reduce of three words, ONE read-back (word 2: error flags of any rank)
+        t = shard.totals_dev(want_dual)
+        if world > 1 or os.environ.get("TD_SHARD_FORCE_AR"):
+            all_reduce(dist, t, SUM)
+        vals = t.tolist()
+        if vals[2] != 0:
+            raise _ffi.TdError("sharded solve: a device-side consistency check failed on some rank (%d flags)" % vals[2])
+        r2c = shard.row_to_col()
+        return (r2c, int(vals[0]), int(vals[1])) if want_dual else (r2c, int(vals[0]))
     tot, dual = shard.totals(want_dual)
     t = shard.scalar_tensor([tot, dual])
     if world > 1:
