@@ -8,6 +8,7 @@ STEPS=10 PMC=1 bash tools/profile_round.sh r4 g1 > /dev/null 2>&1
 cp gpurun_out/prof_r4/summary.json profiles/r4/rocprof_summary_r4_g1.json
 STEPS=10 PMC=1 bash tools/profile_round.sh r4_g3 g3 > /dev/null 2>&1
 STEPS=20 PMC=0 bash tools/profile_round.sh r4_tick tick > /dev/null 2>&1
+mkdir -p gpurun_out/prof_r4_n65536
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r4_n65536/trace -- python3 bench.py --n 65536 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/prof_r4_n65536/trace.log 2>&1
 python3 bench.py --n 65536 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/prof_r4_n65536/bench.json 2> gpurun_out/prof_r4_n65536/bench.err
