@@ -226,6 +226,11 @@ int g_core_k = 64;          // TD_CORE_K        rank of the group minimum that b
 int g_core_min_n = 8192;    // TD_CORE_MIN_N    smallest n it is used for (uniform 0..10^6: n = 4096 9.1 -> 11.4 ms, the dense rounds of 16 KiB rows are cheaper than building the lists; n = 16 384 43.7 -> 32.3 ms)
 int g_core_mode = 1;        // TD_CORE_MODE     1: the lists are taken on trust in the phases whose eps is at most TD_CORE_EPS x their average reach (the earlier phases bid on the dense rows); 0: every phase, a bid only where the list proves the row's best column, the other bidders on their dense rows
 double g_core_eps = 1.0;    // TD_CORE_EPS
+int g_rand_test = 1;        // TD_RAND_TEST     row-correlation test (k_row_corr): random-like matrices get the short eps ladder (TD_RAND_DIV) and TD_RAND_ROUNDS eps = 0 rounds after it
+int g_rand_div = 8192;      // TD_RAND_DIV
+int g_rand_rounds = 48;     // TD_RAND_ROUNDS
+int g_rand_repeat = 1;      // TD_RAND_REPEAT   blocks of TD_RAND_ROUNDS eps = 0 rounds after the warm start
+double g_rand_corr = 0.12;  // TD_RAND_CORR     mean |r| over 64 sampled row pairs below which the matrix counts as random-like (random: ~0.05; metric structure: 0.3 - 0.9)
 int g_core_patience = 6;    // TD_CORE_PATIENCE groups of 8 rounds a phase on trusted lists may take before the lists are dropped for good
 int g_solver_eps = 0;       // TD_SOLVER=eps    literal eps-scaling auction (comparison mode)
 int g_eps_theta = 8;        // TD_EPS_THETA
@@ -294,6 +299,11 @@ void read_tunables()
     if (const char *e = getenv("TD_CORE_MODE")) g_core_mode = atoi(e);
     if (const char *e = getenv("TD_CORE_EPS")) g_core_eps = atof(e);
     if (const char *e = getenv("TD_CORE_PATIENCE")) g_core_patience = std::max(1, atoi(e));
+    if (const char *e = getenv("TD_RAND_TEST")) g_rand_test = atoi(e) != 0;
+    if (const char *e = getenv("TD_RAND_DIV")) g_rand_div = std::max(1, atoi(e));
+    if (const char *e = getenv("TD_RAND_ROUNDS")) g_rand_rounds = std::max(1, std::min(48, atoi(e)));
+    if (const char *e = getenv("TD_RAND_CORR")) g_rand_corr = atof(e);
+    if (const char *e = getenv("TD_RAND_REPEAT")) g_rand_repeat = std::max(1, atoi(e));
     if (const char *e = getenv("TD_BLOCKS")) g_blocks = std::max(-1, std::min(HOP_BMAX, atoi(e)));
     if (const char *e = getenv("TD_BLOCKS_MIN_N")) g_blocks_min_n = std::max(0, atoi(e));
     if (const char *e = getenv("TD_ZS_ROUNDS")) g_zs_rounds = std::max(0, std::min(32, atoi(e)));
@@ -3907,7 +3917,7 @@ int sv_solve_eps_t(Solver &sv, long long eps0_mult, int theta, int64_t *rounds_o
 // feasible, so exactness still rests on the eps = 0 rounds + shortest augmenting paths + the LP
 // certificate that follow; the assignment of the eps phases is thrown away.
 template <typename CT>
-int sv_warm_t(Solver &sv, int64_t range, int64_t *rounds_out)
+int sv_warm_t(Solver &sv, int64_t range, int64_t *rounds_out, bool *random_like = nullptr)
 {
     Ctx &c = ctx();
     using PT = typename Tr<CT>::PT;
@@ -3923,6 +3933,23 @@ int sv_warm_t(Solver &sv, int64_t range, int64_t *rounds_out)
     int64_t core_rounds = 0, miss_total = 0, bids_total = 0;
     bool phase_core = true;
     double t_avg = 0.0;
+    int warm_div = g_warm_div;
+    if (random_like) *random_like = false;
+    if (g_rand_test && sizeof(CT) == 4 && n >= g_core_min_n && sv.nrows == n) {
+        // random-like or metric structure (k_row_corr)?  64 row pairs; the verdict rides on the read-back the lists need anyway
+        double *d_corr = (double *)((char *)sv.misc.p + 2048 + 128);   // 64 doubles, clear of the control words, the totals and t_sum
+        k_row_corr<CT><<<64, 256, 0, c.stream>>>(n, sv.nchunks, (const CT *)sv.cc.p, d_corr);
+        TD_HIP(hipMemcpyAsync((char *)c.pinned + 2048, d_corr, 64 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        TD_HIP(hipStreamSynchronize(c.stream));
+        double m = 0;
+        for (int k = 0; k < 64; k++) m += ((const double *)((const char *)c.pinned + 2048))[k];
+        m /= 64.0;
+        if (getenv("TD_DEBUG")) fprintf(stderr, "[td] row-correlation test: mean |r| = %.3f over 64 row pairs -> %s\n", m, m < g_rand_corr ? "random-like" : "structured");
+        if (m < g_rand_corr) {
+            warm_div = std::max(g_warm_div, g_rand_div);
+            if (random_like) *random_like = true;
+        }
+    }
     if (use_core) {
         int rc;
         if ((rc = ensure(sv.core, sizeof(uint2) * (size_t)n * CORE_CAP))) return rc;
@@ -3941,7 +3968,7 @@ int sv_warm_t(Solver &sv, int64_t range, int64_t *rounds_out)
             t_avg = (double)(((unsigned long long *)c.pinned)[0]) / (double)n;
         }
     }
-    for (long long eps = std::max<long long>(1, range / g_warm_div);; eps = std::max<long long>(eps_last, eps / g_warm_theta)) {
+    for (long long eps = std::max<long long>(1, range / warm_div);; eps = std::max<long long>(eps_last, eps / g_warm_theta)) {
         (void)first;
         k_eps_reset<PT><<<(std::max(n, (int)CTL_WORDS) + 255) / 256, 256, 0, c.stream>>>(n, sv.nrows, (PT *)sv.price.p, (int *)sv.owner.p,
                                                                                            (int *)sv.r2c.p, (int *)sv.misc.p);
@@ -4408,12 +4435,13 @@ restart:
             }
             return TD_OK;
         };
+        bool random_like = false;
         auto warm = [&](int bits) -> int {
             const int keep = g_warm_bits;
             g_warm_bits = bits;
-            if (bpc == 2) rc = sv_warm_t<uint16_t>(sv, known_range, &warm_rounds);
-            else if (bpc == 5) rc = sv_warm_t<u32n>(sv, known_range, &warm_rounds);
-            else rc = sv_warm_t<uint32_t>(sv, known_range, &warm_rounds);
+            if (bpc == 2) rc = sv_warm_t<uint16_t>(sv, known_range, &warm_rounds, &random_like);
+            else if (bpc == 5) rc = sv_warm_t<u32n>(sv, known_range, &warm_rounds, &random_like);
+            else rc = sv_warm_t<uint32_t>(sv, known_range, &warm_rounds, &random_like);
             g_warm_bits = keep;
             return rc;
         };
@@ -4474,7 +4502,12 @@ restart:
             // eps > 0 phases down to eps = 1 as a price warm start (sv_warm_t), the rounds once more,
             // then the dense finisher
             if ((rc = warm(g_warm_bits))) return rc;
+            if (random_like) round_cap = std::max(round_cap, g_rand_rounds);   // (cheap here: a few hundred bidders; halves what is left for the forest)
             if ((rc = rounds(false))) return rc;
+            for (int rep = 1; random_like && rep < g_rand_repeat; rep++) {   // more blocks of eps = 0 rounds (the per-round progress words are reused)
+                TD_HIP(hipMemsetAsync((int *)sv.misc.p + CTL_PROG, 0, sizeof(int) * 64, c.stream));
+                if ((rc = rounds(false))) return rc;
+            }
         }
         ShardTab tab{};
         tab.p[0] = sv.cc.p;

@@ -176,3 +176,39 @@ __global__ __launch_bounds__(1024) void k_price_min(int n, const PT *__restrict_
         *reinterpret_cast<long long *>(&ctl[CTL_COREMISS + 2]) = m;
     }
 }
+
+// Is the matrix "random-like" (independent cells: uniform 0..10^6) or does it have metric structure (2-D grids, |a - b|)?  The
+// warm start's best schedule differs (profiles/r4/general_solver_r4_schedule.txt: random-like rows are fastest when the eps
+// ladder starts at range / 8192 and 48 eps = 0 rounds follow — 32 -> 23 ms at n = 16 384 —, geometric ones need the whole
+// ladder from range / 4: 212 -> 490 ms otherwise) and nothing cheap in the sizes or the value distribution tells them apart
+// (|a - b| on a line has the same linear density of small cells as a random row).  What does: the cost vectors of two ROWS
+// are uncorrelated in a random matrix (|r| ~ 1 / sqrt(samples)) and strongly correlated under any metric.  One workgroup per
+// sampled row pair, 256 sampled columns, Pearson's r in double; the host averages |r| over the pairs.
+template <typename CT>
+__global__ __launch_bounds__(256) void k_row_corr(int n, int nchunks, const CT *__restrict__ cc, double *__restrict__ out)
+{
+    constexpr int E = Tr<CT>::E;
+    __shared__ double s_acc[4][5];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const size_t pitch = (size_t)nchunks * E;
+    const uint32_t h1 = (blockIdx.x + 1u) * 0x9E3779B1u, h2 = (blockIdx.x + 1u) * 0x85EBCA6Bu + 0x27D4EB2Fu;
+    const int i1 = (int)(((uint64_t)(h1 ^ (h1 >> 15)) * (uint64_t)n) >> 32);
+    int i2 = (int)(((uint64_t)(h2 ^ (h2 >> 13)) * (uint64_t)n) >> 32);
+    if (i2 == i1) i2 = (i1 + n / 2) % n;
+    const int j = (int)(((long long)tid * n) >> 8);   // 256 evenly spread columns
+    const double x = (double)(uint32_t)cc[(size_t)i1 * pitch + j], y = (double)(uint32_t)cc[(size_t)i2 * pitch + j];
+    double a[5] = {x, y, x * y, x * x, y * y};
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a[k] += __shfl_xor(a[k], o);
+        if (lane == 0) s_acc[w][k] = a[k];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double t[5];
+        for (int k = 0; k < 5; k++) t[k] = s_acc[0][k] + s_acc[1][k] + s_acc[2][k] + s_acc[3][k];
+        const double m = 256.0, cov = t[2] - t[0] * t[1] / m, vx = t[3] - t[0] * t[0] / m, vy = t[4] - t[1] * t[1] / m;
+        out[blockIdx.x] = (vx > 0 && vy > 0) ? fabs(cov) / sqrt(vx * vy) : 1.0;   // a constant row is not random
+    }
+}
