@@ -58,6 +58,24 @@ def test_tick49_instance_and_general_table(td):
     assert tot == oracle.assign(cost)[0]
 
 
+def test_wide_thresholds_take_the_four_byte_fused_cells(td):
+    """a threshold far above 253: the 1-byte cells + escape of the fused pass do not fit (flag on the device), the pass is redone
+    with 4-byte cells — still made from the position arrays — and the result is td_cost_build + td_assign's"""
+    rng = np.random.default_rng(12)
+    cab_to, dem_from = rng.integers(0, 2000, 5000), rng.integers(0, 2000, 1000)
+    n, r2c, ref, tot, cost, st = _both(td, cab_to, dem_from, None, BIG, 1000)
+    assert st["transposed"] == 1 and st["bytes_per_cell"] == 4
+    assert np.array_equal(r2c, ref)
+    # and a whole 65 536-cab model (4 GiB as int32, never built): optimal by the certificate, every request served by a cab in range
+    cab_to, dem_from = rng.integers(0, 50, 65536), rng.integers(0, 50, 20000)
+    n, r2c, total, dual = td.build_assign(cab_to, dem_from, None, fill=BIG, threshold=10, want_dual=True)
+    assert n == 65536 and total == dual and sorted(r2c.tolist()) == list(range(n))
+    served = r2c[:65536] < 20000
+    assert int(np.abs(cab_to[served] - dem_from[r2c[served]]).clip(max=BIG).sum()) + BIG * int((~served).sum()) >= total
+    real = np.abs(cab_to[served] - dem_from[r2c[served]]) < 10
+    assert total == int(np.abs(cab_to[served] - dem_from[r2c[served]])[real].sum()) + BIG * (65536 - int(real.sum()))
+
+
 @pytest.mark.parametrize("n_s,n_d,thr", [(700, 700, -1), (900, 1400, 10), (64, 20, 10), (1, 1, -1), (5, 0, 10), (2100, 2090, 10)])
 def test_other_shapes_are_built_and_solved_as_before(td, n_s, n_d, thr):
     """square models, dummy CABS, tiny models, an empty side, dummy requests below the shape rule's margin: the matrix is
