@@ -219,6 +219,7 @@ int g_zs_rounds = 4;        // TD_ZS_ROUNDS     local bidding rounds of phase A 
 int g_zs_sep = 0;           // TD_ZS_SEP        rows of <= 16 384 columns: round 0 of phase A as its own launch behind the plain compress pass.  OFF: measured slower (td_assign n = 16 384 0.487 -> 0.543 ms: the plain 256 x 16 pass takes 0.29 ms in this sequence, the pass that also writes the bids 0.243)
 int g_hop_passes = 2;       // TD_HOP_PASSES    two-hop passes at the end of phase A (the second one takes the rows the first pass's greedy left: 4 of 183 at n = 16 384)
 int g_hop_max_rows = HOP_FMAX;   // TD_HOP_MAX_ROWS  a block with more free rows than this is left to the rounds
+int g_lazy_cc = 1;          // TD_LAZY_CC       td_assign, block-local start: the compress pass stores the diagonal slices of the narrow copy only; the rest is written (k_compress_rest) only if phase A + the two-hop pass over the whole matrix leave rows
 int g_hop_global = 1;       // TD_HOP_GLOBAL    td_assign: one two-hop pass over the whole matrix after phase A
 int g_zs_global_rounds = 6; // TD_ZS_GLOBAL_ROUNDS  td_assign: bidding rounds launched for what the block-local start left
 int g_core = 1;             // TD_CORE          the warm start's eps-phases bid on a sparse core of every row (td_core_warm.h)
@@ -311,6 +312,7 @@ void read_tunables()
     if (const char *e = getenv("TD_HOP_PASSES")) g_hop_passes = std::max(0, std::min(8, atoi(e)));
     if (const char *e = getenv("TD_HOP_MAX_ROWS")) g_hop_max_rows = std::max(1, atoi(e));
     if (const char *e = getenv("TD_HOP_GLOBAL")) g_hop_global = atoi(e) != 0;
+    if (const char *e = getenv("TD_LAZY_CC")) g_lazy_cc = atoi(e) != 0;
     if (const char *e = getenv("TD_ZS_GLOBAL_ROUNDS")) g_zs_global_rounds = std::max(1, std::min(48, atoi(e)));
 }
 
@@ -484,6 +486,30 @@ __global__ __launch_bounds__(256) void k_compress(int n, int nrows, int nchunks,
     if (tid == 0 && wmax > 0) atomicMax(reinterpret_cast<unsigned long long *>(&ctl[CTL_RSEEN]), (unsigned long long)wmax);
 }
 
+// The cells k_compress_reg<.., BID0>(diag_only = 1) did not store: every row's narrow cells OUTSIDE its own column slice,
+// from the row minima that pass left (same bytes as the full pass writes).  Launched only when something after phase A
+// needs whole rows of the narrow copy (bidding rounds over whole rows, a finisher, the dual bound).
+__global__ __launch_bounds__(256) void k_compress_rest(int n, int nrows, int row0, int nchunks, int rpb, const int32_t *__restrict__ cost,
+                                                       uint8_t *__restrict__ cc, const int32_t *__restrict__ rowmin,
+                                                       const int *__restrict__ ctl)
+{
+    if (ctl[CTL_FLAG]) return;   // rows too wide for one byte: the attempt is abandoned
+    const int nq = n >> 2, qpb = rpb >> 2;
+    const size_t pitch = (size_t)nchunks * 16;
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int mn = rowmin[row];
+        const int q0 = ((row0 + row) / rpb) * qpb;
+        const int4 *s4 = reinterpret_cast<const int4 *>(cost + (int64_t)row * n);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(cc + (size_t)row * pitch);
+        for (int q = threadIdx.x; q < nq; q += 256) {
+            if ((unsigned)(q - q0) < (unsigned)qpb) continue;
+            const int4 x4 = s4[q];
+            const uint32_t a = (uint32_t)(x4.x - mn), b = (uint32_t)(x4.y - mn), c = (uint32_t)(x4.z - mn), d = (uint32_t)(x4.w - mn);
+            dst[q] = (a & 0xFF) | ((b & 0xFF) << 8) | ((c & 0xFF) << 16) | (d << 24);
+        }
+    }
+}
+
 // Register-resident variant: the row is read ONCE from HBM (all VPT 16-byte loads of a thread
 // are issued back to back, so a 256-thread workgroup keeps 64 KiB in flight), reduced, and
 // written back narrow.  Needs n % 4 == 0, a 16-byte aligned matrix and n/4 <= THREADS*VPT.
@@ -502,7 +528,9 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(
     int *__restrict__ r2c = nullptr /* BID0: constant rows are deferred (-2) */,
     int probe_tickets = 0 /* BID0: > 0 = take a ticket of the shape probe at the end */,
     int zs_rpb = 0 /* BID0: > 0 = block-local start (td_blocks.h): rows per diagonal block; a row bids for the first ZERO cell of
-                      its own column slice only, never raising a price */)
+                      its own column slice only, never raising a price */,
+    int diag_only = 0 /* BID0 + zs_rpb: 1 = store the narrow cells of the row's OWN column slice only (1/V of the copy: all that
+                         phase A reads); k_compress_rest writes the rest if anything after phase A needs whole rows */)
 {
     static_assert(!BID0 || sizeof(CT) == 1, "round 0 out of the compress pass: 1-byte cells");
     if (skip && *skip) return;
@@ -645,18 +673,19 @@ __global__ __launch_bounds__(THREADS) void k_compress_reg(
                                d = (uint32_t)(x4.w - mn);
                 if constexpr (sizeof(CT) == 1) {
                     const uint32_t word = (a & 0xFF) | ((b & 0xFF) << 8) | ((c & 0xFF) << 16) | (d << 24);
-                    reinterpret_cast<uint32_t *>(dst)[q] = word;
                     if constexpr (BID0) {
+                        const bool in_slice = !zs_rpb || (unsigned)((q >> 2) - zc0) < (unsigned)zcpb;
+                        if (!diag_only || in_slice) reinterpret_cast<uint32_t *>(dst)[q] = word;
                         // 0x80 in every byte of `word` that is zero (exact: no borrow between bytes)
                         // (branch-free: a divergent branch here makes the compiler wait for every store before the next)
                         const uint32_t z = ~(((word & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | word | 0x7F7F7F7Fu);
                         int t = (q >> 2) - zc0 - rot;   // position of the word's chunk in the row's rotated order
-                        const bool in_slice = !zs_rpb || (unsigned)((q >> 2) - zc0) < (unsigned)zcpb;
                         t += t < 0 ? (zs_rpb ? zcpb : nchunks) : 0;
                         const int cand = t * 16 + (q & 3) * 4 + (__builtin_ctz(z | 0x80000000u) >> 3);
                         fp = min(fp, (z && in_slice) ? cand : INT_MAX);
                         c0 += __builtin_popcount(z);
-                    }
+                    } else
+                        reinterpret_cast<uint32_t *>(dst)[q] = word;
                 } else if constexpr (sizeof(CT) == 2) {
                     reinterpret_cast<uint2 *>(dst)[q] = make_uint2((a & 0xFFFF) | (b << 16), (c & 0xFFFF) | (d << 16));
                 } else {
@@ -3143,6 +3172,9 @@ struct td_shard {
     bool tick_sized = false;   // td_tick's remainder (hinted, n < 2048): the rounds leave a dozen rows, the serial workgroup is through before a speculative batch + its commit are — no read-back of the free-row count to decide that
     int zs_V = 0;              // diagonal blocks of the whole matrix the 1-byte attempt may start in (0: off)
     bool zs_done = false;      // the compress pass prepared the block-local start (wrote the zero-slice bids of phase A's round 0, or left them to k_zs_bid: zs_round0): sv_phase_a is due
+    bool lazy_cc = false;      // td_assign: the block-local start may leave the narrow copy with the diagonal slices only (k_compress_reg diag_only)
+    bool cc_partial = false;   // ... and this attempt's copy IS partial: whoever needs whole rows calls sv_complete_cc first
+    int cc_rpb = 0;
     bool zs_round0 = false;    // ... round 0 of phase A is still to be bid (rows of <= 16 384 columns: the plain compress pass + one k_zs_bid round over 1/8 of every row beat the pass that also scans for the bids, 216 + ~10 against 243 us)
     bool began = false;        // the state (prices, owners, row_to_col, bid keys) has been initialised for the current compressed copy
     bool state_ready = false;  // sharded solve: the state was initialised in front of the compress pass and phase A has run on it (td_shard_begin must not redo it)
@@ -3208,6 +3240,7 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
     sv.zs_done = false;
     sv.zs_round0 = false;
     sv.began = false;
+    sv.cc_partial = false;
     if (nrows > 0) {
         const int nq = n / 4;
         CT *cc = (CT *)sv.cc.p;
@@ -3232,6 +3265,12 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
             sv.zs_round0 = true;
         }
         const bool bid0_kernel = bid0 && !zs_sep;
+        // the narrow cells outside the diagonal slices are only read if phase A leaves rows: do not write them until then
+        // (7/8 of the 0.25 GiB copy at n = 16 384)
+        const int diag = (sizeof(CT) == 1 && sv.lazy_cc && g_lazy_cc && bid0_kernel && zs_rpb > 0 && sv.d_cost && !sv.gen) ? 1 : 0;
+        // (one WAVE per row with only the slice waiting in registers — no LDS, no barrier — was built and measured: 284 - 390 us
+        // against 215 for this pass at n = 16 384, slower the more waves stream at once: thousands of concurrent 64-KiB
+        // row streams in 8-KiB steps cost DRAM page locality that whole-row requests of a workgroup keep)
         static const int gbm = getenv("TD_BID0_GRID") ? atoi(getenv("TD_BID0_GRID")) : 0;
         const int gb = std::max(1, std::min(nrows, c.n_cu * (gbm > 0 ? gbm : std::max(1, g_cgrid / 2))));   // 512-thread workgroups of the BID0 pass
         if (bid0_kernel) {
@@ -3262,11 +3301,13 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
                     static const int shape = getenv("TD_BID0_SHAPE") ? atoi(getenv("TD_BID0_SHAPE")) : 0;
                     if (shape == 1)
                         k_compress_reg<CT, 4, 1024, true><<<gb, 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
-                                                                                    sv.row0, defer_r2c, tickets, zs_rpb);
+                                                                                    sv.row0, defer_r2c, tickets, zs_rpb, diag);
                     else
                         k_compress_reg<CT, 8, 512, true><<<gb, 512, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
-                                                                                   sv.row0, defer_r2c, tickets, zs_rpb);
+                                                                                   sv.row0, defer_r2c, tickets, zs_rpb, diag);
                     sv.zs_done = zs_rpb > 0;
+                    sv.cc_partial = diag != 0;
+                    sv.cc_rpb = zs_rpb;
                 }
             } else {
                 static const int cshape = getenv("TD_CREG_SHAPE") ? atoi(getenv("TD_CREG_SHAPE")) : 0;
@@ -3287,16 +3328,18 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
                         const int shm = 8 * 1024 * 16;
                         (void)hipFuncSetAttribute((const void *)k_compress_reg<CT, 16, 1024, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
                         k_compress_reg<CT, 16, 1024, true, 8><<<g4, 1024, shm, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
-                                                                                          sv.row0, defer_r2c, tickets, zs_rpb);
+                                                                                          sv.row0, defer_r2c, tickets, zs_rpb, diag);
                     } else if (clds == 4) {
                         const int shm = 4 * 1024 * 16;
                         (void)hipFuncSetAttribute((const void *)k_compress_reg<CT, 16, 1024, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
                         k_compress_reg<CT, 16, 1024, true, 4><<<g4, 1024, shm, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
-                                                                                          sv.row0, defer_r2c, tickets, zs_rpb);
+                                                                                          sv.row0, defer_r2c, tickets, zs_rpb, diag);
                     } else
                         k_compress_reg<CT, 16, 1024, true><<<g4, 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip, bidp,
-                                                                                      sv.row0, defer_r2c, tickets, zs_rpb);
+                                                                                      sv.row0, defer_r2c, tickets, zs_rpb, diag);
                     sv.zs_done = zs_rpb > 0;
+                    sv.cc_partial = diag != 0;
+                    sv.cc_rpb = zs_rpb;
                 }
             } else
                 k_compress_reg<CT, 16, 1024><<<g4, 1024, 0, c.stream>>>(n, nrows, nchunks, sv.d_cost, cc, rm, ctl, rcs, sv.skip);
@@ -3416,8 +3459,24 @@ int sv_compress_fused(Solver &sv, bool *fits, int64_t *range, bool cells8 = fals
 }
 
 // One two-hop pass (td_blocks.h) over `nb` blocks of rpb rows x ncols_blk columns starting at column col_lo.
+// The rest of a narrow copy whose compress pass stored the diagonal slices only (k_compress_reg diag_only).
+int sv_complete_cc(Solver &sv)
+{
+    if (!sv.cc_partial) return TD_OK;
+    Ctx &c = ctx();
+    ProfScope ps(TD_K_COMPRESS);
+    k_compress_rest<<<std::max(1, std::min(sv.nrows, c.n_cu * 8)), 256, 0, c.stream>>>(sv.n, sv.nrows, sv.row0, sv.nchunks, sv.cc_rpb, sv.d_cost,
+                                                                                      (uint8_t *)sv.cc.p, (const int32_t *)sv.rowmin.p,
+                                                                                      (const int *)sv.misc.p);
+    TD_HIP(hipGetLastError());
+    sv.cc_partial = false;
+    return TD_OK;
+}
+
+// raw: the cells come from the caller's int32 matrix and the row minima (a solve whose narrow copy holds the diagonal
+// slices only, sv.cc_partial)
 template <typename CT>
-int sv_hop_t(Solver &sv, int rpb, int ncols_blk, int col_lo, int nb, bool window_zero, uint8_t *ob)
+int sv_hop_t(Solver &sv, int rpb, int ncols_blk, int col_lo, int nb, bool window_zero, uint8_t *ob, bool raw = false)
 {
     Ctx &c = ctx();
     using PT = typename Tr<CT>::PT;
@@ -3429,6 +3488,16 @@ int sv_hop_t(Solver &sv, int rpb, int ncols_blk, int col_lo, int nb, bool window
     int *frl = (int *)sv.list.p, *fcl = (int *)sv.pred.p;   // free until the finisher
     const int *ctl = (const int *)sv.misc.p;
     k_hop_lists<<<nb, 1024, 0, c.stream>>>(rpb, ncols_blk, col_lo, (const int *)sv.r2c.p, (const int *)sv.owner.p, frl, fcl, hc, ctl);
+    if (raw) {
+        if (!sv.d_cost || sv.n % 4) return fail(TD_EINVAL, "two-hop pass on the int32 matrix: no matrix, or n %% 4 != 0");
+        k_hop_esc<CT, true><<<(sv.nrows + 3) / 4, 256, 0, c.stream>>>(sv.nrows, sv.n / 4, rpb, ncols_blk, col_lo, g_hop_max_rows,
+                                                                      (const CT *)sv.d_cost, (const PT *)sv.price.p, (const int *)sv.r2c.p, fcl,
+                                                                      hc, (unsigned long long *)sv.esc.p, ctl, (const int32_t *)sv.rowmin.p);
+        k_hop_table<CT, true><<<nb * HOP_FMAX, 256, 0, c.stream>>>(sv.n, sv.nrows, sv.row0, sv.n / 4, rpb, ncols_blk, col_lo, g_hop_max_rows,
+                                                                   window_zero ? 1 : 0, (const CT *)sv.d_cost, (const PT *)sv.price.p,
+                                                                   (const int *)sv.owner.p, frl, hc, (const unsigned long long *)sv.esc.p,
+                                                                   (int *)sv.hoptab.p, ctl, (const int32_t *)sv.rowmin.p);
+    } else {
     k_hop_esc<CT><<<(sv.nrows + 3) / 4, 256, 0, c.stream>>>(sv.nrows, sv.nchunks, rpb, ncols_blk, col_lo, g_hop_max_rows, (const CT *)sv.cc.p,
                                                             (const PT *)sv.price.p, (const int *)sv.r2c.p, fcl, hc,
                                                             (unsigned long long *)sv.esc.p, ctl);
@@ -3436,6 +3505,7 @@ int sv_hop_t(Solver &sv, int rpb, int ncols_blk, int col_lo, int nb, bool window
                                                          window_zero ? 1 : 0, (const CT *)sv.cc.p, (const PT *)sv.price.p,
                                                          (const int *)sv.owner.p, frl, hc, (const unsigned long long *)sv.esc.p,
                                                          (int *)sv.hoptab.p, ctl);
+    }
     k_hop_match<PT><<<nb, HOP_FMAX, sizeof(uint32_t) * (size_t)((rpb + 31) / 32), c.stream>>>(
         sv.nrows, sv.row0, rpb, ncols_blk, col_lo, g_hop_max_rows, (PT *)sv.price.p, (int *)sv.owner.p, (int *)sv.r2c.p, ob, frl, fcl, hc,
         (const int *)sv.hoptab.p, (int *)sv.misc.p);
@@ -4276,6 +4346,7 @@ restart:
     compress_pass:
         if (sv.fused_t) {   // cc already holds the transposed problem (k_compress_tr); the same bytes serve both price widths
             sv.bid0_done = false;   // (a 1-byte attempt queued before the fused pass may have set it)
+            sv.cc_partial = false;
             sv.zs_done = false;
             fits = true;
             sv.bpc = bpc;
@@ -4283,11 +4354,13 @@ restart:
         } else {
             // 1-byte attempt: state init + the shape probe ride in front of the compress pass, which writes round 0's bids
             sv.want_bid0 = spec && !g_solver_eps;
+            sv.lazy_cc = true;
             sv.zs_V = (sv.want_bid0 && orient == 0) ? (g_blocks >= 0 ? g_blocks : (n >= g_blocks_min_n ? 8 : 0)) : 0;
             sv.probe = (spec && orient == 0 && g_shape && n >= 64 && n <= g_shape_max_n && !g_solver_eps) ? sv.d_cost : nullptr;
             sv.range_seen = -1;
             rc = sv_compress(sv, bpc, &fits, spec);
             sv.want_bid0 = false;
+            sv.lazy_cc = false;
             sv.probe = nullptr;
             if (rc) return rc;
             // a width that fits after a mere lower bound of the range (the line probe's "row 0 is too wide for one byte"):
@@ -4465,7 +4538,8 @@ restart:
                 if ((rc = read_left())) return rc;
                 if (getenv("TD_DEBUG")) fprintf(stderr, "[td] after the block-local start: %d rows free, flag %d\n", pin[0], pin[1]);
                 if (pin[0] > 0 && pin[1] == 0 && g_hop_global && pin[0] <= g_hop_max_rows) {
-                    if ((rc = sv_hop_t<uint8_t>(sv, n, n, 0, 1, false, nullptr))) return rc;
+                    // (nothing has moved a price yet: "tight" is "zero cell" over the whole row too, and the pass needs no row minimum)
+                    if ((rc = sv_hop_t<uint8_t>(sv, n, n, 0, 1, true, nullptr, sv.cc_partial))) return rc;
                     if ((rc = read_left())) return rc;
                     if (getenv("TD_DEBUG")) fprintf(stderr, "[td] after the two-hop pass over the whole matrix: %d rows free\n", pin[0]);
                 }
@@ -4473,6 +4547,7 @@ restart:
                 round_cap = std::min(max_rounds, g_zs_global_rounds);
             }
         }
+        if (!all_placed && (rc = sv_complete_cc(sv))) return rc;   // the rounds and the finishers read whole rows of the narrow copy
         if (!all_placed && (rc = rounds(true))) return rc;
         // Wide, tie-free rows (no constant rows, few rows tied at their minimum) that the eps = 0
         // rounds leave with many free rows.  One small read-back; only non-speculative attempts
@@ -4521,6 +4596,7 @@ restart:
             k_place_const<<<1, 1024, 0, c.stream>>>(n, (int *)sv.r2c.p, (int *)sv.owner.p, (int *)sv.list.p, (int *)sv.pred.p,
                                                    (int *)sv.misc.p);
         }
+        if (dual_bound != nullptr && (rc = sv_complete_cc(sv))) return rc;   // (k_dual reads the narrow rows)
         TD_DISPATCH(sv, sv_totals_t, sv, dual_bound != nullptr);
         if (rc) return rc;
         int flag = 0;
@@ -4810,6 +4886,10 @@ int td_shard_options(td_shard *s, int flags)
     // bit 1: block-local start (td_blocks.h) — the 1-byte compress pass writes zero-slice bids, td_shard_phase_a runs the
     // local rounds and the two-hop pass, td_shard_state_export / _import carry the ONE exchange that follows
     s->zs_V = ((flags & 3) == 3 && s->want_bid0) ? (g_blocks > 0 ? g_blocks : (g_blocks < 0 ? 8 : 0)) : 0;
+    // bit 2: with the block-local start, the compress pass stores the narrow cells of the diagonal slices only; the library
+    // writes the rest by itself (k_compress_rest) the first time a call needs whole rows: td_shard_bid / _rounds / _cc /
+    // _finish, the dual bound of td_shard_total(_dev)
+    s->lazy_cc = (flags & 4) != 0 && s->zs_V > 0;
     return TD_OK;
 }
 
@@ -4964,6 +5044,7 @@ namespace {
 int shard_bid_round(td_shard *s, int round, unsigned long long *keys)
 {
     int rc = TD_OK;
+    if ((rc = sv_complete_cc(*s))) return rc;   // a lazy narrow copy (td_shard_options bit 2): the rounds read whole rows
     if (round == 0 && s->bid0_done) {
         const size_t bytes = sizeof(unsigned long long) * (size_t)s->npad;
         TD_HIP(hipMemcpyAsync(keys, s->bid.p, bytes, hipMemcpyDeviceToDevice, ctx().stream));
@@ -5103,6 +5184,10 @@ int td_shard_cc(td_shard *s, void **ptr, uint64_t *bytes)
 {
     TD_REQUIRE_INIT();
     if (!s || !s->bpc) return fail(TD_EINVAL, "shard not compressed");
+    {
+        const int rc = sv_complete_cc(*s);   // whoever asks for the rows (the finisher's rank, a gathered copy) gets whole rows
+        if (rc) return rc;
+    }
     if (ptr) *ptr = s->cc.p;
     if (bytes) *bytes = (uint64_t)s->nrows * s->nchunks * 16;
     return TD_OK;
@@ -5193,6 +5278,7 @@ int td_shard_total(td_shard *s, int64_t *partial_total, int64_t *partial_dual)
     TD_REQUIRE_INIT();
     if (!s) return fail(TD_EINVAL, "null shard");
     int rc;
+    if (partial_dual != nullptr && (rc = sv_complete_cc(*s))) return rc;
     TD_HIP(hipMemsetAsync((char *)s->misc.p + 1024, 0, 16, ctx().stream));
     TD_DISPATCH(*s, sv_totals_t, *s, partial_dual != nullptr);
     if (rc) return rc;
@@ -5210,6 +5296,7 @@ int td_shard_total_dev(td_shard *s, int64_t *out3, int want_dual)
     if (!s || !out3) return fail(TD_EINVAL, "null argument");
     if (!is_device_ptr(out3)) return fail(TD_EINVAL, "td_shard_total_dev: the three words must be device memory");
     int rc;
+    if (want_dual && (rc = sv_complete_cc(*s))) return rc;
     TD_HIP(hipMemsetAsync((char *)s->misc.p + 1024, 0, 16, c.stream));
     TD_DISPATCH(*s, sv_totals_t, *s, want_dual != 0);
     if (rc) return rc;

@@ -142,12 +142,14 @@ __global__ __launch_bounds__(1024) void k_hop_lists(int rpb, int ncols_blk, int 
 }
 
 // ---- two hops: which free columns of its block is an assigned row tight to (one wave per row)
-template <typename CT>
+// RAW: `cc` is the caller's int32 matrix (row pitch = nchunks * 4 = n) and a cell is c - rowmin[row]: the same value the
+// narrow copy holds, for a solve whose compress pass stored the diagonal slices only (k_compress_reg diag_only).
+template <typename CT, bool RAW = false>
 __global__ __launch_bounds__(256) void k_hop_esc(int nrows, int nchunks, int rpb, int ncols_blk, int col_lo, int max_rows,
                                                  const CT *__restrict__ cc, const typename Tr<CT>::PT *__restrict__ pk,
                                                  const int *__restrict__ r2c, const int *__restrict__ fcl,
                                                  const HopCtl *__restrict__ hc, unsigned long long *__restrict__ esc,
-                                                 const int *__restrict__ ctl)
+                                                 const int *__restrict__ ctl, const int32_t *__restrict__ rowmin = nullptr)
 {
     using PT = typename Tr<CT>::PT;
     if (ctl[CTL_FLAG]) return;
@@ -161,19 +163,25 @@ __global__ __launch_bounds__(256) void k_hop_esc(int nrows, int nchunks, int rpb
     const int j = r2c[lrow];
     unsigned long long m0 = 0, m1 = 0;
     if (j >= 0) {
-        const size_t pitch = (size_t)nchunks * Tr<CT>::E;
-        const CT *rp = cc + (size_t)lrow * pitch;
-        const long long u = (long long)(uint32_t)rp[j] + (long long)(pk[j] >> 1);   // the row's dual (its pair is tight)
+        const size_t pitch = (size_t)nchunks * (RAW ? 4 : Tr<CT>::E);
+        const CT *rp = cc + (RAW ? 0 : (size_t)lrow * pitch);
+        const int32_t *rr = reinterpret_cast<const int32_t *>(cc) + (RAW ? (size_t)lrow * pitch : 0);
+        const int32_t mn = RAW ? rowmin[lrow] : 0;
+        auto cell = [&](int col) -> long long {
+            if constexpr (RAW) return (long long)(uint32_t)(rr[col] - mn);
+            else return (long long)(uint32_t)rp[col];
+        };
+        const long long u = cell(j) + (long long)(pk[j] >> 1);   // the row's dual (its pair is tight)
         const int *fc = fcl + (size_t)lb * ncols_blk;
         const int cb = col_lo + lb * ncols_blk;
         bool t0 = false, t1 = false;
         if (lane < nfc) {
             const int jb = cb + fc[lane];
-            t0 = (long long)(uint32_t)rp[jb] + (long long)(pk[jb] >> 1) == u;
+            t0 = cell(jb) + (long long)(pk[jb] >> 1) == u;
         }
         if (lane + 64 < nfc) {
             const int jb = cb + fc[lane + 64];
-            t1 = (long long)(uint32_t)rp[jb] + (long long)(pk[jb] >> 1) == u;
+            t1 = cell(jb) + (long long)(pk[jb] >> 1) == u;
         }
         m0 = __ballot(t0);
         m1 = __ballot(t1);
@@ -190,20 +198,21 @@ __global__ __launch_bounds__(256) void k_hop_esc(int nrows, int nchunks, int rpb
 // The row is taken in segments of 256 chunks (one per thread): the tight cells of a segment go to a list in LDS first
 // (a thread-private walk over its 16 cells with three dependent loads behind every hit cost 16 serialised load chains
 // per wave: 19 us for a 2048-column slice), then all 256 threads take list entries — owner, escape masks, atomicMin into
-// the table row.  A segment holds at most 256 * E candidates: the list cannot overflow, the result does not depend on
-// the order of the appends.
-template <typename CT>
+// the table row.  A segment holds at most 256 * E (RAW: 256 * 4 * 4) candidates: the list cannot overflow, the result
+// does not depend on the order of the appends.
+template <typename CT, bool RAW = false>
 __global__ __launch_bounds__(256) void k_hop_table(int n, int nrows, int row0, int nchunks, int rpb, int ncols_blk, int col_lo,
                                                    int max_rows, int window_zero, const CT *__restrict__ cc,
                                                    const typename Tr<CT>::PT *__restrict__ pk, const int *__restrict__ owner,
                                                    const int *__restrict__ frl, const HopCtl *__restrict__ hc,
                                                    const unsigned long long *__restrict__ esc, int *__restrict__ tab,
-                                                   const int *__restrict__ ctl)
+                                                   const int *__restrict__ ctl, const int32_t *__restrict__ rowmin = nullptr)
 {
     using PT = typename Tr<CT>::PT;
-    constexpr int E = Tr<CT>::E;
+    constexpr int E = RAW ? 4 : Tr<CT>::E;   // cells per 16 bytes (RAW: the int32 matrix itself, nchunks = n / 4, see k_hop_esc)
     __shared__ int s_tab[HOP_FMAX];
-    __shared__ int s_cand[256 * E];
+    constexpr int CHT = RAW ? 4 : 1;   // 16-byte pieces per thread and segment (RAW: 4 cells a piece, the same 4096-entry list as 1-byte cells)
+    __shared__ int s_cand[256 * E * CHT];
     __shared__ int s_ncand;
     __shared__ long long s_v[4];
     if (ctl[CTL_FLAG]) return;
@@ -213,7 +222,15 @@ __global__ __launch_bounds__(256) void k_hop_table(int n, int nrows, int row0, i
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lrow = lb * rpb + frl[(size_t)lb * rpb + a];
     const size_t pitch = (size_t)nchunks * E;
-    const CT *rp = cc + (size_t)lrow * pitch;
+    const unsigned char *rp = reinterpret_cast<const unsigned char *>(cc) + (size_t)lrow * pitch * (RAW ? 4 : sizeof(CT));
+    const int32_t mn = RAW ? rowmin[lrow] : 0;
+    auto cells = [&](const uint4 &raw, uint32_t *c) {
+        if constexpr (RAW) {
+            c[0] = (uint32_t)((int32_t)raw.x - mn), c[1] = (uint32_t)((int32_t)raw.y - mn);
+            c[2] = (uint32_t)((int32_t)raw.z - mn), c[3] = (uint32_t)((int32_t)raw.w - mn);
+        } else
+            unpack<CT>(raw, c);
+    };
     if (tid < HOP_FMAX) s_tab[tid] = INT_MAX;
     if (tid == 0) s_ncand = 0;
     // the row's columns in question: its block's slice (phase A) or all of them
@@ -224,7 +241,7 @@ __global__ __launch_bounds__(256) void k_hop_table(int n, int nrows, int row0, i
         long long mv = LLONG_MAX;
         for (int t = tid; t < ch_n; t += 256) {
             uint32_t c[E];
-            unpack<CT>(*reinterpret_cast<const uint4 *>(rp + (size_t)(ch_lo + t) * E), c);
+            cells(*reinterpret_cast<const uint4 *>(rp + (size_t)(ch_lo + t) * 16), c);
             PT pv[E];
             const int j0 = (ch_lo + t) * E;
             if constexpr (sizeof(PT) == 4) {
@@ -252,16 +269,24 @@ __global__ __launch_bounds__(256) void k_hop_table(int n, int nrows, int row0, i
         v = min(min(s_v[0], s_v[1]), min(s_v[2], s_v[3]));
     }
     __syncthreads();
-    for (int t0 = 0; t0 < ch_n; t0 += 256) {
-        const int t = t0 + tid;
+    for (int t0 = 0; t0 < ch_n; t0 += 256 * CHT) {
+        uint4 raws[CHT];
+#pragma unroll
+        for (int u = 0; u < CHT; u++) {
+            const int t = t0 + u * 256 + tid;
+            if (t < ch_n) raws[u] = *reinterpret_cast<const uint4 *>(rp + (size_t)(ch_lo + t) * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < CHT; u++) {
+        const int t = t0 + u * 256 + tid;
         if (t < ch_n) {
-            const uint4 raw = *reinterpret_cast<const uint4 *>(rp + (size_t)(ch_lo + t) * E);
+            const uint4 raw = raws[u];
             bool any = true;
-            if constexpr (sizeof(CT) == 1 && std::is_same<CT, uint8_t>::value)   // (a zero cell is a zero byte)
+            if constexpr (!RAW && sizeof(CT) == 1 && std::is_same<CT, uint8_t>::value)   // (a zero cell is a zero byte)
                 if (window_zero) any = (zs_zero_bytes(raw.x) | zs_zero_bytes(raw.y) | zs_zero_bytes(raw.z) | zs_zero_bytes(raw.w)) != 0;
             if (any) {
                 uint32_t c[E];
-                unpack<CT>(raw, c);
+                cells(raw, c);
                 PT pv[E];
                 const int j0 = (ch_lo + t) * E;
                 if constexpr (sizeof(PT) == 4) {
@@ -281,6 +306,7 @@ __global__ __launch_bounds__(256) void k_hop_table(int n, int nrows, int row0, i
                     if (tight) s_cand[atomicAdd(&s_ncand, 1)] = j0 + e;
                 }
             }
+        }
         }
         __syncthreads();
         const int nc = s_ncand;

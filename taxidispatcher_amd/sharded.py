@@ -256,7 +256,8 @@ class HipShard:
 
     # -- block-local start (csrc/td_blocks.h): phase A on the shard's own diagonal blocks, then ONE exchange
     def blocks_start(self, on=True):
-        _ffi.check(self.lib.td_shard_options(self.h, 3 if on else 1))
+        lazy = 4 if os.environ.get("TD_LAZY_CC", "1") != "0" else 0   # the narrow copy outside the diagonal slices only if phase A leaves rows
+        _ffi.check(self.lib.td_shard_options(self.h, (3 | lazy) if on else 1))
 
     def compress_spec(self):
         """the 1-byte compress pass of the block-local start without waiting for its width flag (it travels in the segment)"""

@@ -105,7 +105,7 @@ static int32_t *pc, *root, *own, *inF, *dirty, *need, *urgent;
 /* global arrays (other workgroups read them) */
 static LT *g_base; static int32_t *g_root, *g_col, *g_pc;
 static long st_levels, st_rowscans, st_ends, st_endsteps, st_repair_rows, st_reopen, st_emptylv;
-static int verbose, LO = 32, HI = 256; static long dbg_urg, dbg_above, dbg_below, dbg_rel; static LT dbg_mfree;
+static int verbose, LO = 32, HI = 256, QDIV = 0, RELMAX = 8; static long st_exts; static long dbg_urg, dbg_above, dbg_below, dbg_rel; static LT dbg_mfree;
 
 static void relax(int w, const Ent *E, int m)
 {
@@ -199,7 +199,8 @@ static void forest(LT W0)
 #pragma omp parallel for
     for (int w = 0; w < G; w++) relax_all(w);
     st_rowscans += nfree;
-    LT W = W0, gdlo = 0, gmfree = INF; int gate = 0, tight = 0;   /* first board: headers only */
+    LT W = W0, gdlo = 0, gmfree = INF, ext = 0; int gate = 0, tight = 0, ext_on = 0;   /* first board: headers only */
+    LT *srt = malloc(sizeof(LT) * G);
     long guard = 0;
     int32_t *path = malloc(4 * (n + 1)), *rl = malloc(4 * n), *oldown = malloc(4 * n);
     while (nfree > 0) {
@@ -207,6 +208,7 @@ static void forest(LT W0)
         LT thr = (gdlo >= INF) ? INF : (gdlo <= -INF ? -INF : gdlo + W);
         { static LT WX = -1; if (WX < 0) WX = getenv("WX") ? atoll(getenv("WX")) : 16; if (gmfree < INF && thr > gmfree + WX) thr = gmfree + WX; }
         if (tight) thr = gmfree;
+        if (ext_on) { thr = (gdlo >= INF) ? INF : (gdlo <= -INF ? -INF : gdlo + W); if (thr > ext || tight) thr = ext; }   /* deferred END: everything below ext */
         dbg_mfree = INF; for (int j = 0; j < n; j++) if (own[j] < 0 && lab[j] < dbg_mfree) dbg_mfree = lab[j];
         for (int w = 0; w < G; w++) select_wg(w, gate, thr, board + (size_t)w * CAP, hdr + w);
         /* ---- barrier; everybody reads the board */
@@ -225,21 +227,30 @@ static void forest(LT W0)
              * nothing left open the next selection takes whatever opened below the smallest free label + W */
             gdlo = ndlo; gmfree = nmf; gate = 1;
             tight = !(ndlo < nmf) && nmf < INF;   /* nothing known open below the free label: take only what opened below it */
-            if (ndlo >= INF) gdlo = nmf;
+            if (ext_on) tight = !(ndlo < ext);
+            if (ndlo >= INF) gdlo = ext_on ? ext : nmf;
             continue;
         }
         st_emptylv++;
-        if (ndlo < nmf) { gdlo = ndlo; gmfree = nmf; gate = 1; tight = 0; continue; }   /* gate was closed, work appeared */
+        if (ndlo < (ext_on ? ext : nmf)) { gdlo = ndlo; gmfree = nmf; gate = 1; tight = 0; continue; }   /* gate was closed, work appeared */
         if (nmf >= INF) { fprintf(stderr, "no path (nfree=%d)\n", nfree); exit(3); }
+        if (!ext_on && QDIV > 0 && nfree > 1) {   /* would-be END at nmf: defer it to the q-th smallest free label the headers know */
+            int q = nfree / QDIV; if (q < 1) q = 1; if (q > RELMAX) q = RELMAX;
+            int m = 0; for (int w = 0; w < G; w++) if (hdr[w].minfree < INF) srt[m++] = hdr[w].minfree;
+            for (int a = 1; a < m; a++) { LT v = srt[a]; int b = a - 1; while (b >= 0 && srt[b] > v) { srt[b + 1] = srt[b]; b--; } srt[b + 1] = v; }
+            const LT tgt = srt[(q - 1 < m) ? q - 1 : m - 1];
+            if (tgt > nmf) { ext = tgt; ext_on = 1; st_exts++; gdlo = (ndlo >= INF) ? ext : ndlo; gmfree = nmf; gate = 1; tight = !(ndlo < ext); continue; }
+        }
         /* ---- END at D: workgroup 0 flips the paths */
         st_endsteps++;
-        const LT D = nmf;
+        const LT D = ext_on ? ext : nmf;   /* every label below D is exact; free labels <= D are exact */
+        ext_on = 0;
         int nrl = 0;
         for (int w = 0; w < G; w++) for (int e = 0; e < hdr[w].nend; e++) {
-            if (hdr[w].minfree != D) continue;
+            if (hdr[w].minfree > D) continue;
             const int r = hdr[w].eroot[e]; int dup = 0;
             for (int k = 0; k < nrl; k++) if (rl[k] == r) dup = 1;
-            if (dup || nrl >= 8) continue;
+            if (dup || nrl >= RELMAX) continue;
             rl[nrl++] = r;
             int len = 0, j = hdr[w].ecol[e];
             while (j >= 0) { path[len++] = j; j = g_pc[j]; if (len > n) { fprintf(stderr, "path cycle at END D=%ld root %d\n", (long)D, r);
@@ -256,6 +267,7 @@ static void forest(LT W0)
             if (lab[j] < INF) for (int k = 0; k < nrl; k++) if (root[j] == rl[k]) hit = 1;
             if (hit) {
                 if (inF[j]) { if (lab[j] < D) price[j] += D - lab[j]; g_base[own[j]] = INF; inF[j] = 0; dirty[j] = 0; urgent[j] = 0; dbg_rel++; }
+                else if (own[j] < 0 && lab[j] < D) price[j] += D - lab[j];   /* a free column inside the settled part of a released tree */
                 lab[j] = INF; pc[j] = -1; g_pc[j] = -1; root[j] = -1; need[j] = 1;
             }
             if (own[j] != owner[j]) { own[j] = owner[j]; cown[j] = c[(int64_t)own[j] * n + j]; }
@@ -265,7 +277,7 @@ static void forest(LT W0)
             int any = 0; for (int j = w * CW; j < (w + 1) * CW && j < n; j++) if (need[j]) { any = 1; need[j] = 0; }
             if (any) relax_all(w);
         }
-        gdlo = D; gmfree = D; gate = 1; tight = 0;   /* the next free label is not known yet: stay within WX of the last one */
+        gdlo = nmf; gmfree = nmf; gate = 1; tight = 0;   /* the next free label is not known yet: stay within WX of the last one */
         if (verbose) printf("   END D=%ld: %d trees, free=%d levels=%ld W=%ld\n", (long)D, nrl, nfree, st_levels, (long)W);
     }
     for (int j = 0; j < n; j++) p[j] = price[j];
@@ -283,7 +295,9 @@ int main(int argc, char **argv)
     if (argc > 8) CAP = atoi(argv[8]);
     verbose = argc > 9 ? atoi(argv[9]) : 0;
     if (getenv("LO")) LO = atoi(getenv("LO")); if (getenv("HI")) HI = atoi(getenv("HI"));
+    if (getenv("QDIV")) QDIV = atoi(getenv("QDIV")); if (getenv("RELMAX")) RELMAX = atoi(getenv("RELMAX"));
     c = gen(kind, n, seed);
+    if (getenv("SCALE")) { const int K = atoi(getenv("SCALE")); int32_t *cw = (int32_t *)c; for (int64_t k = 0; k < (int64_t)n * n; k++) cw[k] *= K; }
     p = calloc(n, 8); r2c = malloc(4 * n); owner = malloc(4 * n); list = malloc(4 * n); pick = malloc(4 * n);
     bidv = malloc(8 * n); bidr = malloc(4 * n);
     for (int i = 0; i < n; i++) { r2c[i] = owner[i] = -1; list[i] = i; }
@@ -295,7 +309,20 @@ int main(int argc, char **argv)
         for (;;) {
             for (int i = 0; i < n; i++) { r2c[i] = owner[i] = -1; list[i] = i; } U = n;
             int r = 0; while (U > n / 64 && r < 256) { U = jacobi_round(U, eps); r++; }
-            if (eps == 1) break;
+            if (eps == 1) {
+                if (getenv("PURE")) {   /* eps-scaling to the end on costs * K, K > n: run the last phase out, no exact finisher */
+                    long r0 = st_rounds, s0 = st_scans, tail = 0;
+                    while (U > 0) { if (U <= n / 64) tail++; U = jacobi_round(U, eps); }
+                    int64_t tot = 0; for (int i = 0; i < n; i++) tot += c[(int64_t)i * n + r2c[i]];
+                    int64_t lb = 0; for (int i = 0; i < n; i++) { int64_t m = INT64_MAX; for (int j = 0; j < n; j++) { int64_t v = c[(int64_t)i * n + j] + p[j]; if (v < m) m = v; } lb += m; }
+                    for (int j = 0; j < n; j++) lb -= p[j];
+                    const int K = atoi(getenv("SCALE"));
+                    printf("PURE: rounds=%ld (last phase %ld, of them %ld with <= n/64 bidders), row scans/n=%.2f (last phase %.2f) total=%ld (/K = %ld rem %ld) gap to the dual bound=%ld (K=%d) %s\n",
+                           st_rounds, st_rounds - r0 + r, tail, (double)st_scans / n, (double)(st_scans - s0) / n, (long)tot, (long)(tot / K), (long)(tot % K), (long)(tot - lb), K, (tot - lb < K) ? "PROVEN" : "unproven");
+                    return 0;
+                }
+                break;
+            }
             eps /= warm; if (eps < 1) eps = 1;
         }
         for (int i = 0; i < n; i++) { r2c[i] = owner[i] = -1; list[i] = i; } U = n;
@@ -319,6 +346,7 @@ int main(int argc, char **argv)
     printf("%s n=%d W0=%ld CW=%d CAP=%d: total=%ld dual=%ld %s infeasible=%ld notperm=%ld | levels=%ld empty=%ld endsteps=%ld ends=%ld rowscans/n=%.2f reopen/n=%.2f repair_rows/n=%.2f\n",
            kind, n, (long)W0, CW, CAP, (long)tot, (long)dual, (tot == dual && !bad && !perm) ? "OK" : "MISMATCH", bad, perm,
            st_levels, st_emptylv, st_endsteps, st_ends, (double)st_rowscans / n, (double)st_reopen / n, (double)st_repair_rows / n / G);
+    printf("   deferred ENDs: %ld\n", st_exts);
     printf("   fresh joins: below mfree %.1f/n, above %.1f/n ; released forest cols %.1f/n\n", (double)dbg_below / n, (double)dbg_above / n, (double)dbg_rel / n);
     return (tot == dual && !bad && !perm) ? 0 : 1;
 }
