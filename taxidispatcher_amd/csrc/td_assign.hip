@@ -3268,9 +3268,10 @@ int sv_compress_t(Solver &sv, bool *fits, bool speculate = false)
         // the narrow cells outside the diagonal slices are only read if phase A leaves rows: do not write them until then
         // (7/8 of the 0.25 GiB copy at n = 16 384)
         const int diag = (sizeof(CT) == 1 && sv.lazy_cc && g_lazy_cc && bid0_kernel && zs_rpb > 0 && sv.d_cost && !sv.gen) ? 1 : 0;
-        // (one WAVE per row with only the slice waiting in registers — no LDS, no barrier — was built and measured: 284 - 390 us
-        // against 215 for this pass at n = 16 384, slower the more waves stream at once: thousands of concurrent 64-KiB
-        // row streams in 8-KiB steps cost DRAM page locality that whole-row requests of a workgroup keep)
+        // (two restructurings of the diag_only pass were built and measured at n = 16 384, both SLOWER than this pass's
+        // 215 us: one WAVE per row with only the slice waiting in registers — no LDS, no barrier — 284 - 390 us, slower the
+        // more waves stream at once; the next row's loads issued before the barrier, so that every workgroup has a row
+        // in flight all the time, 267 - 288 us.  More bytes in flight do not help this pass)
         static const int gbm = getenv("TD_BID0_GRID") ? atoi(getenv("TD_BID0_GRID")) : 0;
         const int gb = std::max(1, std::min(nrows, c.n_cu * (gbm > 0 ? gbm : std::max(1, g_cgrid / 2))));   // 512-thread workgroups of the BID0 pass
         if (bid0_kernel) {

@@ -100,3 +100,60 @@ def test_round0_out_of_the_compress_pass_is_bit_identical(td):
         res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
     assert res["1"] == res["0"]
     assert len(res["1"]) == 7
+
+
+_LAZY_CHILD = r"""
+import sys, json, hashlib
+sys.path.insert(0, %r)
+import numpy as np, torch
+import taxidispatcher_amd as td
+td.init(0)
+out = {}
+g = torch.Generator(device="cuda").manual_seed(11)
+for name, n in [("g1", 12288), ("g1", 16384), ("uniq", 12288), ("wide8", 12288), ("padboth", 16384), ("g4", 12288), ("sparse0", 16384)]:
+    if name == "g4":
+        c = torch.randint(0, 4, (n, n), dtype=torch.int32, device="cuda", generator=g)
+    elif name == "uniq":      # ONE cell at the minimum of every row: the block-local start places few rows
+        c = torch.randint(3, 200, (n, n), dtype=torch.int32, device="cuda", generator=g)
+        c[torch.arange(n, device="cuda"), torch.randint(0, n, (n,), device="cuda", generator=g)] = 0
+        c[::7] += 1000
+    elif name == "wide8":     # ~ n / 250 zero cells per row
+        c = torch.randint(-125, 125, (n, n), dtype=torch.int32, device="cuda", generator=g)
+    elif name == "sparse0":   # zero cells mostly OUTSIDE the diagonal blocks: the two-hop pass over the whole matrix has work
+        c = torch.randint(1, 60, (n, n), dtype=torch.int32, device="cuda", generator=g)
+        cols = (torch.arange(n, device="cuda") * 7919 + 4321) %% n
+        for k in range(6):
+            c[torch.arange(n, device="cuda"), (cols + k * 2731) %% n] = 0
+    else:
+        c = torch.randint(10, 41, (n, n), dtype=torch.int32, device="cuda", generator=g)
+        if name == "padboth":
+            c[torch.randperm(n, device="cuda", generator=g)[:n // 5]] = 250
+            c[:, torch.randperm(n, device="cuda", generator=g)[:n // 3]] = 250
+    for want_dual in (False, True):
+        got = td.assign(c, want_dual=want_dual)
+        r2c, tot = got[0], got[1]
+        assert sorted(np.asarray(r2c).tolist()) == list(range(n))
+        assert int(c[torch.arange(n, device="cuda"), torch.as_tensor(np.asarray(r2c), device="cuda").long()].sum().item()) == tot
+        if want_dual:
+            assert got[2] == tot
+        out["%%s_%%d_%%d" %% (name, n, int(want_dual))] = [int(tot), hashlib.sha1(np.asarray(r2c).tobytes()).hexdigest()]
+print(json.dumps(out))
+""" % ROOT
+
+
+@pytest.mark.gpu
+def test_lazy_narrow_copy_is_bit_identical(td):
+    """TD_LAZY_CC=1 (the compress pass of the block-local start stores the diagonal slices of the 1-byte copy only, the
+    two-hop pass over the whole matrix reads the int32 matrix, k_compress_rest writes the other cells when rows are left
+    or the dual bound is asked for) against TD_LAZY_CC=0 (the whole copy at once): the same row_to_col bit for bit, with
+    and without the dual bound, on families where phase A places everything, nearly nothing, and where the zero cells lie
+    outside the diagonal blocks."""
+    import json
+    res = {}
+    for mode in ("1", "0"):
+        env = dict(os.environ, TD_LAZY_CC=mode)
+        r = subprocess.run([sys.executable, "-c", _LAZY_CHILD], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["1"] == res["0"]
+    assert len(res["1"]) == 14
