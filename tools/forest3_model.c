@@ -7,6 +7,16 @@
  * row scans and END events.
  * build: gcc -O3 -fopenmp -o /tmp/forest3 tools/forest3_model.c
  * usage: forest3 kind n arr_rounds warm seed W0 [CW] [CAP] [verbose]
+ * Round-4 experiments behind environment variables (none of them is in the kernel; DESIGN.md 2.12 has the outcomes):
+ *   SCALE=K        costs * K before the warm start, i.e. an eps ladder that ends at 1/K of a cost unit: the rows the
+ *                  eps = 0 rounds leave for the forest do NOT get fewer (g2d n = 4096: 251 / 245 / 261 / 259 for K = 1 / 4 / 16 / 64)
+ *   PURE=1 SCALE=n+1   eps-scaling run to the end (eps < 1/n, no exact finisher): the last phase's tail did not end
+ *                  within 20 minutes at n = 4096
+ *   QDIV=d RELMAX=m    deferred END: at a would-be END the forest grows on to the (free rows / d)-th smallest free label
+ *                  the headers know and releases up to m trees at once (prices of a released tree's free columns are raised
+ *                  too).  g2d n = 2048: ENDs 38 -> 16, levels 495 -> 438, exact; at n = 8192 it runs into the level guard
+ *                  (unfinished: an END below the deferred label is needed when trees are left over).  Levels are dependency
+ *                  depth, not END count — not pursued.
  */
 #include <stdint.h>
 #include <stdio.h>
