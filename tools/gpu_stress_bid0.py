@@ -40,7 +40,11 @@ while time.time() < t_end and cnt < max_cnt:
             c[torch.randperm(n, device="cuda")[: int(rng.integers(1, n // 2))]] = 250
         if kind in ("padcols", "padboth"):
             c[:, torch.randperm(n, device="cuda")[: int(rng.integers(1, n // 2))]] = 250
+    first = td.assign(c, n) if os.environ.get("STRESS_BOTH") else None   # without the dual bound first: a lazy narrow copy (TD_LAZY_CC) then stays partial when phase A places every row
     r2c, tot, dual = td.assign(c, n, want_dual=True)
+    if first is not None and not (first[1] == tot and np.array_equal(np.asarray(first[0]), np.asarray(r2c))):
+        bad += 1
+        print("FAIL (with / without the dual bound differ)", kind, n, first[1], tot, flush=True)
     r = torch.from_numpy(np.asarray(r2c)).cuda().long()
     ok = tot == dual and bool((torch.sort(r).values == torch.arange(n, device="cuda")).all()) and \
         int(c[torch.arange(n, device="cuda"), r].long().sum().item()) == tot
