@@ -311,8 +311,8 @@ TD_API int td_shard_row_to_col(td_shard *s, int32_t *r2c_local);
  * The ordinary rounds (td_shard_bid / _apply / _rounds) and td_shard_finish take what is still free; when
  * summary[2] == 0 the solve is complete.  flags bit 2 (flags = 7): the compress pass stores the 1-byte cells of the
  * diagonal slices only (all that phase A reads: 1/8 of the narrow copy); the library writes the other cells by itself
- * the first time a call needs whole rows (td_shard_bid / _rounds / _cc / _finish, the dual bound of td_shard_total) —
- * never, when phase A leaves nothing.  td_assign starts the same way for n >= 12 288 (td_set_blocks),
+ * the first time a call needs whole rows (td_shard_bid / _rounds, td_shard_cc — where the pointers td_shard_finish reads
+ * through come from —, the dual bound of td_shard_total) — never, when phase A leaves nothing.  td_assign starts the same way for n >= 12 288 (td_set_blocks),
  * so a sharded run and td_assign with the same block count stay bit-identical. */
 TD_API int td_shard_compress_spec(td_shard *s);   /* the 1-byte compress pass without waiting for its width flag (it travels in the segment) */
 TD_API int td_shard_blocks_pending(td_shard *s);

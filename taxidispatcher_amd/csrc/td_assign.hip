@@ -4888,8 +4888,8 @@ int td_shard_options(td_shard *s, int flags)
     // local rounds and the two-hop pass, td_shard_state_export / _import carry the ONE exchange that follows
     s->zs_V = ((flags & 3) == 3 && s->want_bid0) ? (g_blocks > 0 ? g_blocks : (g_blocks < 0 ? 8 : 0)) : 0;
     // bit 2: with the block-local start, the compress pass stores the narrow cells of the diagonal slices only; the library
-    // writes the rest by itself (k_compress_rest) the first time a call needs whole rows: td_shard_bid / _rounds / _cc /
-    // _finish, the dual bound of td_shard_total(_dev)
+    // writes the rest by itself (k_compress_rest) the first time a call needs whole rows: td_shard_bid / _rounds, td_shard_cc
+    // (the source of every pointer td_shard_finish reads through), the dual bound of td_shard_total(_dev)
     s->lazy_cc = (flags & 4) != 0 && s->zs_V > 0;
     return TD_OK;
 }
